@@ -1,0 +1,176 @@
+"""ctypes front end of the CPU oracle (oracle/zdr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+``cpu_baseline`` leg of bench.py — never by anything under zdr_amd/.
+PARITY UNPINNED at the LuisaCompute boundary (see zdr_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+COLLOCATED, DIRECT, PATH = 0, 1, 2
+SAMPLER_CMJ, SAMPLER_PMJ02BN = 0, 1
+PRB_CORRECT, PRB_LITERAL = 0, 1
+INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH}
+COUNTER_NAMES = ("samples", "closest_rays", "closest_hits", "shadow_rays", "shaded_vertices",
+                 "emitter_hits_bsdf", "nan_samples", "grad_scatters")
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("integrator", C.c_int32), ("sampler", C.c_int32),
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("spp", C.c_uint32), ("seed", C.c_uint32),
+        ("use_tent", C.c_int32),
+        ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
+        ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
+        ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("prb_mode", C.c_int32),
+        ("cam_fov", C.c_float), ("cam_origin", C.c_float * 3), ("cam_target", C.c_float * 3), ("cam_up", C.c_float * 3),
+        ("tex_h", C.c_int32), ("tex_w", C.c_int32), ("nthreads", C.c_int32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libzdr_oracle.so")
+    src = os.path.join(_HERE, "zdr_oracle.c")
+    hdr = os.path.join(_HERE, "zdr_oracle.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["make", "-C", _HERE, "-B", "libzdr_oracle.so"], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.zdro_scene_create.restype = C.c_void_p
+        L.zdro_scene_create.argtypes = [fp, C.c_int, ip, C.c_int, ip, fp, fp, C.c_int]
+        L.zdro_scene_destroy.argtypes = [C.c_void_p]
+        L.zdro_scene_set_emissions.argtypes = [C.c_void_p, fp]
+        L.zdro_render_forward.argtypes = [C.c_void_p, C.POINTER(Params), fp, fp, C.POINTER(C.c_uint64)]
+        L.zdro_render_backward.argtypes = [C.c_void_p, C.POINTER(Params), fp, fp, fp, C.POINTER(C.c_uint64)]
+        L.zdro_trace_closest.argtypes = [C.c_void_p, fp, C.c_int, ip, fp]
+        L.zdro_trace_any.argtypes = [C.c_void_p, fp, C.c_int, ip]
+        L.zdro_xxhash32_4.restype = C.c_uint32
+        L.zdro_xxhash32_4.argtypes = [C.c_uint32] * 4
+        L.zdro_permutation_element.restype = C.c_uint32
+        L.zdro_permutation_element.argtypes = [C.c_uint32] * 4
+        L.zdro_sampler_dump.restype = C.c_int
+        L.zdro_sampler_dump.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, fp]
+        L.zdro_ggx_brdf.argtypes = [fp, fp, fp, C.c_float, fp]
+        L.zdro_ggx_sample_pdf.restype = C.c_float
+        L.zdro_ggx_sample_pdf.argtypes = [fp, fp, C.c_float]
+        L.zdro_ggx_sample.argtypes = [fp, C.c_float, C.c_float, fp, fp]
+        L.zdro_ggx_brdf_grad.argtypes = [fp, fp, fp, C.c_float, fp, fp]
+        L.zdro_generate_ray.argtypes = [C.POINTER(Params), C.c_float, C.c_float, fp, fp]
+        L.zdro_offset_ray_origin.argtypes = [fp, fp, fp]
+        L.zdro_read_bsdf.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float, fp]
+        L.zdro_set_pmj02bn_tables.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(c) for c in v])
+
+
+def make_params(integrator, width, height, spp, seed, camera, tex_hw, *, sampler=SAMPLER_CMJ, use_tent=True,
+                rect=None, samples=None, max_depth=16, rr_depth=2, prb_mode=PRB_CORRECT, nthreads=0) -> Params:
+    """camera = (fov, origin, target, up) or an object with those attributes."""
+    if not isinstance(camera, (tuple, list)):
+        camera = (camera.fov, tuple(camera.origin), tuple(camera.target), tuple(camera.up))
+    p = Params()
+    p.integrator = INTEGRATORS[integrator] if isinstance(integrator, str) else int(integrator)
+    p.sampler = sampler
+    p.width, p.height, p.spp, p.seed = width, height, spp, seed & 0xFFFFFFFF
+    p.use_tent = int(bool(use_tent))
+    p.x0, p.y0, p.x1, p.y1 = rect if rect is not None else (0, 0, width, height)
+    p.sample_begin, p.sample_end = samples if samples is not None else (0, spp)
+    p.max_depth, p.rr_depth, p.prb_mode = max_depth, rr_depth, prb_mode
+    p.cam_fov = camera[0]
+    p.cam_origin, p.cam_target, p.cam_up = f3(camera[1]), f3(camera[2]), f3(camera[3])
+    p.tex_h, p.tex_w = tex_hw
+    p.nthreads = nthreads
+    return p
+
+
+class OracleScene:
+    """CPU twin of zdr_amd.Scene's native handle, built from zdr_amd.geometry.SceneArrays-like arrays."""
+
+    def __init__(self, verts, tris, inst_tri_begin, inst_xform, inst_emission):
+        self._keep = [np.ascontiguousarray(verts, np.float32), np.ascontiguousarray(tris, np.int32),
+                      np.ascontiguousarray(inst_tri_begin, np.int32), np.ascontiguousarray(inst_xform, np.float32),
+                      np.ascontiguousarray(inst_emission, np.float32)]
+        v, t, b, x, e = self._keep
+        self.ninst = e.reshape(-1, 3).shape[0]
+        self.h = lib().zdro_scene_create(_f(v), v.reshape(-1, 8).shape[0], _i(t), t.reshape(-1, 3).shape[0], _i(b), _f(x), _f(e), self.ninst)
+
+    @classmethod
+    def from_arrays(cls, A):
+        return cls(A.verts, A.tris, A.inst_tri_begin, A.inst_xform, A.inst_emission)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().zdro_scene_destroy(self.h)
+            self.h = None
+
+    def set_emissions(self, e):
+        e = np.ascontiguousarray(e, np.float32).reshape(self.ninst, 3)
+        lib().zdro_scene_set_emissions(self.h, _f(e))
+
+    def render_forward(self, params: Params, material: np.ndarray, counters: bool = False):
+        material = np.ascontiguousarray(material, np.float32)
+        assert material.ndim == 3 and material.shape[2] == 4
+        img = np.zeros((params.height, params.width, 4), np.float32)
+        cnt = (C.c_uint64 * 8)()
+        rc = lib().zdro_render_forward(self.h, C.byref(params), _f(material), _f(img), cnt)
+        if rc:
+            raise RuntimeError(f"oracle forward failed rc={rc}")
+        return (img, dict(zip(COUNTER_NAMES, list(cnt)))) if counters else img
+
+    def render_backward(self, params: Params, d_image: np.ndarray, material: np.ndarray, counters: bool = False):
+        material = np.ascontiguousarray(material, np.float32)
+        d_image = np.ascontiguousarray(d_image, np.float32)
+        assert d_image.shape == (params.height, params.width, 4)
+        dm = np.zeros_like(material)
+        cnt = (C.c_uint64 * 8)()
+        rc = lib().zdro_render_backward(self.h, C.byref(params), _f(d_image), _f(material), _f(dm), cnt)
+        if rc:
+            raise RuntimeError(f"oracle backward failed rc={rc}")
+        return (dm, dict(zip(COUNTER_NAMES, list(cnt)))) if counters else dm
+
+    def trace_closest(self, rays: np.ndarray):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        ip = np.zeros((n, 2), np.int32)
+        bt = np.zeros((n, 3), np.float32)
+        lib().zdro_trace_closest(self.h, _f(rays), n, _i(ip), _f(bt))
+        return ip, bt
+
+    def trace_any(self, rays: np.ndarray):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        occ = np.zeros(rays.shape[0], np.int32)
+        lib().zdro_trace_any(self.h, _f(rays), rays.shape[0], _i(occ))
+        return occ
+
+
+def sampler_dump(kind, px, py, seed, spp, sample_index, nvert=3, rr_depth=2) -> np.ndarray:
+    out = np.zeros(2 + 8 * nvert, np.float32)
+    n = lib().zdro_sampler_dump(kind, px, py, seed & 0xFFFFFFFF, spp, sample_index, nvert, rr_depth, _f(out))
+    return out[:n].copy()

@@ -1,0 +1,128 @@
+/* zdr.h — C-ABI of libzdr_hip.so, the MI355X (gfx950) back end of the zdr render()/PRB hot path.
+ *
+ * This is the drop-in boundary: everything the reference's
+ * `Scene.render_forward` / `Scene.render_backward` (/root/reference/render.py:159-199) obtain
+ * from LuisaCompute — BVH build, ray traversal, the fused integrator kernels, in-kernel
+ * autodiff and the float atomic scatter — sits behind these entry points.  Plain pointers and
+ * sizes only; no torch types.  Device pointers are BORROWED for the duration of a call; work
+ * is enqueued on `stream` (a hipStream_t, NULL = the default stream) and NOT synchronised:
+ * the caller decides when to wait (the reference synchronises on both sides, render.py:165,172).
+ *
+ * All functions return 0 on success or a negative ZDR_E_* code; zdr_last_error() gives the
+ * thread-local message.  One in-flight call per scene handle (render.py:216-222: the
+ * reference scene is not re-entrant either).
+ */
+#ifndef ZDR_H
+#define ZDR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZDR_VERSION_STRING "zdr-mi355x 0.1 (gfx950)"
+
+enum { ZDR_OK = 0, ZDR_E_INVALID = -1, ZDR_E_HIP = -2, ZDR_E_UNSUPPORTED = -3, ZDR_E_NOMEM = -4 };
+
+/* integrators = render.py:65-69 */
+enum { ZDR_COLLOCATED = 0, ZDR_DIRECT = 1, ZDR_PATH = 2 };
+/* samplers = integrator.py:16-17 (corrmj.py is self-contained; pmj02bn.py needs tables) */
+enum { ZDR_SAMPLER_CMJ = 0, ZDR_SAMPLER_PMJ02BN = 1 };
+/* acceleration structure used for LuisaCompute's Accel (render.py:74,109,127) */
+enum { ZDR_ACCEL_AUTO = 0, ZDR_ACCEL_BRUTE = 1, ZDR_ACCEL_BVH = 2 };
+
+typedef struct zdr_scene zdr_scene;
+
+/* render.py:28 — Camera = StructType(fov, origin, target, up); fov = full horizontal angle (rad) */
+typedef struct {
+    float fov;
+    float origin[3], target[3], up[3];
+} zdr_camera;
+
+/* Arguments of one kernel dispatch (integrator.py:10-11, render.py:168-171,193-196) plus the
+ * shard this call covers: a pixel rectangle and a sample-index range. */
+typedef struct {
+    int32_t integrator;                /* ZDR_COLLOCATED | ZDR_DIRECT | ZDR_PATH */
+    int32_t sampler;                   /* ZDR_SAMPLER_* */
+    int32_t width, height;             /* res = (W, H); image tensor is (H, W, 4) */
+    uint32_t spp, seed;                /* backward: the caller passes seed + 1 (render.py:196) */
+    int32_t use_tent;                  /* scene.use_tent_filter (render.py:71) */
+    int32_t x0, y0, x1, y1;            /* pixels [x0,x1) x [y0,y1) are rendered, others untouched */
+    uint32_t sample_begin, sample_end; /* sample indices [begin,end) of [0,spp) are evaluated */
+    int32_t max_depth, rr_depth;       /* prb.py:15-16: 16, 2 */
+    zdr_camera camera;
+    int32_t tex_h, tex_w;              /* material tensor is (tex_h, tex_w, 4) float32 */
+} zdr_render_params;
+
+typedef struct {
+    uint32_t ntris, nverts, ninst, light_count;
+    int32_t accel;                     /* ZDR_ACCEL_BRUTE or ZDR_ACCEL_BVH actually in use */
+    uint32_t bvh_nodes, bvh_max_depth;
+    int32_t device;
+    uint64_t device_bytes;             /* HBM held by the scene */
+} zdr_scene_info_t;
+
+const char *zdr_version(void);
+const char *zdr_last_error(void);
+
+/* Replaces Scene.load_geometry (render.py:73-128): luisa.Buffer uploads, accel.add(vb, tb,
+ * transform), heap.emplace(...), accel.update().  HOST inputs:
+ *   verts8          nverts x 8 float32  {v[3], vt[2], vn[3]} in object space (vertex.py:4)
+ *   tris            ntris  x 3 int32    indices into verts8
+ *   inst_tri_begin  ninst + 1 int32     triangles [begin[i], begin[i+1]) belong to instance i
+ *   inst_xform      ninst x 16 float32  row-major object->world 4x4 (NULL = identity)
+ *   inst_emission   ninst x 3 float32   (render.py:85-91; a light is any emission component > 0)
+ * Only instance 0 is textured; every other instance is an emitter or a blocker (prb.py:45). */
+int zdr_scene_create(const float *verts8, uint32_t nverts, const int32_t *tris, uint32_t ntris,
+                     const int32_t *inst_tri_begin, const float *inst_xform, const float *inst_emission,
+                     uint32_t ninst, int device, int accel, zdr_scene **out);
+int zdr_scene_destroy(zdr_scene *scene);
+int zdr_scene_info(const zdr_scene *scene, zdr_scene_info_t *info);
+
+/* Replaces Scene.update_lights (render.py:130-148). HOST input ninst x 3; rebuilds the light list. */
+int zdr_scene_set_emissions(zdr_scene *scene, const float *inst_emission, void *stream);
+
+/* Tables of the PMJ02bn sampler (pmj02bn.py:9-18; the reference's own are absent,
+ * .MISSING_LARGE_BLOBS).  HOST inputs, copied to the device: pmj [nsets][nsamples][2] uint32
+ * (value / 2^32), bn [ntex][res][res] uint16 (value / 2^16). */
+int zdr_scene_set_pmj02bn_tables(zdr_scene *scene, const uint32_t *pmj, uint32_t nsets, uint32_t nsamples,
+                                 const uint16_t *bn, uint32_t ntex, uint32_t bnres);
+
+/* Replaces Scene.render_forward (render.py:159-173) = render_{path,direct,collocated}_kernel
+ * (integrator.py:9-30).  material: DEVICE (tex_h, tex_w, 4) float32; image: DEVICE (H, W, 4)
+ * float32, pixels of the shard are overwritten with (sum over the sample range / spp,
+ * (sample_end - sample_begin) / spp). */
+int zdr_render_forward(zdr_scene *scene, const zdr_render_params *params, const float *material,
+                       float *image, void *stream);
+
+/* Replaces Scene.render_backward (render.py:176-199) = render_*_backward_kernel
+ * (integrator.py:33-53): d_material (DEVICE, tex_h x tex_w x 4) is ACCUMULATED into (+=), as the
+ * reference's atomic_fetch_add does (interaction.py:63-70); the caller zeroes it (render.py:220).
+ * d_image: DEVICE (H, W, 4) cotangent of the image. */
+int zdr_render_backward(zdr_scene *scene, const zdr_render_params *params, const float *d_image,
+                        const float *material, float *d_material, void *stream);
+
+/* Path statistics of one forward pass over the shard: counters[8] (HOST, written
+ * after an internal synchronise) = camera samples, closest-hit rays, closest rays that hit,
+ * shadow rays, shaded vertices, emitter hits via BSDF sampling, NaN-dropped samples, 0. */
+int zdr_render_stats(zdr_scene *scene, const zdr_render_params *params, const float *material,
+                     uint64_t counters[8], void *stream);
+
+/* LuisaCompute Accel.trace_closest / trace_any (prb.py:25,59) as batch queries, for testing the
+ * acceleration structure.  DEVICE rays: n x 8 {o[3], tmin, d[3], tmax}.
+ * inst_prim: n x 2 int32 (-1,-1 on miss); bary_t: n x 3 float32 {u, v, t}; occluded: n int32. */
+int zdr_trace_closest(zdr_scene *scene, const float *rays, uint32_t n, int32_t *inst_prim, float *bary_t, void *stream);
+int zdr_trace_any(zdr_scene *scene, const float *rays, uint32_t n, int32_t *occluded, void *stream);
+
+/* Sampler values as the kernels draw them, for bit-exact comparison with the oracle
+ * (BASELINE.json: "sample indices bit-exact").  For each of n queries {px, py, sample_index}
+ * (DEVICE int32 n x 3) writes 2 + 8*nvert float32 to out (DEVICE, stride 2 + 8*nvert): next2f,
+ * then per vertex next,next,next2f,next,next2f and — for vertices k >= rr_depth — next
+ * (SURVEY App. A.8); unused slots are 0. */
+int zdr_sampler_dump(zdr_scene *scene, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries,
+                     uint32_t n, int32_t nvert, int32_t rr_depth, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+"""-m gpu: forward images and gradients of the HIP path (called through the C-ABI) against the CPU
+oracle on the same seeded inputs; shard unions; the autograd boundary (render.py:201-241)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import CBOX_CAMERA, cbox_material_np, fd_material_np
+from gpu_util import (TERRAIN_CAMERA, assert_grad_parity, assert_image_parity, make_scene, oracle_params, terrain_arrays)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mat_a():
+    return cbox_material_np()
+
+
+@pytest.fixture(scope="module")
+def mat_b():
+    return fd_material_np(256, 0)
+
+
+@pytest.mark.parametrize("integrator,W,spp", [("collocated", 256, 1), ("direct", 128, 16), ("path", 128, 16), ("path", 64, 64)])
+@pytest.mark.parametrize("accel", ["brute", "bvh"])
+def test_forward_matches_oracle(integrator, W, spp, accel, cbox_oracle, mat_a):
+    scene = make_scene(integrator, accel=accel)
+    m = torch.from_numpy(mat_a).cuda()
+    img = scene.render(m, res=(W, W), spp=spp, seed=0).cpu().numpy()
+    ref = cbox_oracle.render_forward(oracle_params(scene, W, W, spp, 0, mat_a.shape[:2]), mat_a)
+    assert (img[..., 3] == 1.0).all()
+    assert_image_parity(img[..., :3], ref[..., :3], f"{integrator}/{accel} {W}x{W} spp{spp}")
+
+
+def test_forward_box_filter_and_other_seed(cbox_oracle, mat_b):
+    scene = make_scene("path")
+    scene.use_tent_filter = False
+    m = torch.from_numpy(mat_b).cuda()
+    img = scene.render(m, res=(96, 96), spp=16, seed=12345).cpu().numpy()
+    ref = cbox_oracle.render_forward(oracle_params(scene, 96, 96, 16, 12345, mat_b.shape[:2]), mat_b)
+    assert_image_parity(img[..., :3], ref[..., :3], "path box-filter seed 12345")
+
+
+@pytest.mark.parametrize("integrator", ["collocated", "direct", "path"])
+def test_backward_matches_oracle(integrator, cbox_oracle, mat_b):
+    scene = make_scene(integrator)
+    W, spp, seed = 96, 16, 5
+    rng = np.random.default_rng(1)
+    cot = rng.uniform(0.5, 1.5, (W, W, 4)).astype(np.float32)
+    m = torch.from_numpy(mat_b).cuda().requires_grad_()
+    img = scene.render(m, res=(W, W), spp=spp, seed=seed)
+    (img * torch.from_numpy(cot).cuda()).sum().backward()
+    # the reference renders the backward pass with seed + 1 (render.py:196)
+    ref = cbox_oracle.render_backward(oracle_params(scene, W, W, spp, seed + 1, mat_b.shape[:2]), cot, mat_b)
+    assert_grad_parity(m.grad.cpu().numpy(), ref, f"backward {integrator}")
+
+
+def test_backward_bvh_path(cbox_oracle, mat_b):
+    scene = make_scene("path", accel="bvh")
+    W, spp, seed = 64, 16, 9
+    m = torch.from_numpy(mat_b).cuda().requires_grad_()
+    scene.render(m, res=(W, W), spp=spp, seed=seed).sum().backward()
+    ref = cbox_oracle.render_backward(oracle_params(scene, W, W, spp, seed + 1, mat_b.shape[:2]), np.ones((W, W, 4), np.float32), mat_b)
+    assert_grad_parity(m.grad.cpu().numpy(), ref, "backward path/bvh")
+
+
+def test_terrain_scene_forward_and_backward():
+    A = terrain_arrays(n=40)
+    S = oracle.OracleScene.from_arrays(A)
+    scene = make_scene("path", arrays=A)
+    scene.camera = TERRAIN_CAMERA
+    mat = fd_material_np(128, 3)
+    W, spp = 64, 16
+    m = torch.from_numpy(mat).cuda().requires_grad_()
+    img = scene.render(m, res=(W, W), spp=spp, seed=2)
+    ref = S.render_forward(oracle_params(scene, W, W, spp, 2, mat.shape[:2]), mat)
+    assert ref[..., :3].mean() > 0.01
+    assert_image_parity(img.detach().cpu().numpy()[..., :3], ref[..., :3], "terrain path forward")
+    img.sum().backward()
+    gref = S.render_backward(oracle_params(scene, W, W, spp, 3, mat.shape[:2]), np.ones((W, W, 4), np.float32), mat)
+    assert_grad_parity(m.grad.cpu().numpy(), gref, "terrain path backward")
+
+
+def test_shard_unions(mat_a):
+    scene = make_scene("path")
+    m = torch.from_numpy(mat_a).cuda()
+    W, spp = 64, 64
+    full = scene.render_forward(m, (W, W), spp, 4)
+    tiles = torch.zeros_like(full)
+    for rect in [(0, 0, 40, 64), (40, 0, 64, 24), (40, 24, 64, 64)]:
+        scene.render_forward(m, (W, W), spp, 4, rect=rect, out=tiles)
+    assert torch.equal(tiles, full)                              # pixel tiles: bit-for-bit
+    acc = torch.zeros_like(full)
+    for s in [(0, 16), (16, 48), (48, 64)]:
+        acc += scene.render_forward(m, (W, W), spp, 4, samples=s)
+    torch.testing.assert_close(acc, full, rtol=1e-5, atol=1e-6)  # sample ranges: re-association only
+    g_full = torch.zeros_like(m); g_acc = torch.zeros_like(m)
+    ones = torch.ones_like(full)
+    scene.render_backward(ones, g_full, m, (W, W), spp, 4)
+    for rect in [(0, 0, 64, 32), (0, 32, 64, 64)]:
+        scene.render_backward(ones, g_acc, m, (W, W), spp, 4, rect=rect)
+    torch.testing.assert_close(g_acc, g_full, rtol=1e-4, atol=1e-6)
+
+
+def test_stats_match_oracle_counters(cbox_oracle, mat_a):
+    scene = make_scene("path")
+    m = torch.from_numpy(mat_a).cuda()
+    got = scene.render_stats(m, (64, 64), 16, seed=0)
+    _, ref = cbox_oracle.render_forward(oracle_params(scene, 64, 64, 16, 0, mat_a.shape[:2]), mat_a, counters=True)
+    for k in ("samples", "closest_rays", "closest_hits", "shadow_rays", "shaded_vertices", "emitter_hits_bsdf"):
+        assert abs(got[k] - ref[k]) <= max(3, 1e-3 * ref[k]), (k, got[k], ref[k])
+    assert got["samples"] == 64 * 64 * 16
+
+
+def test_autograd_boundary_semantics(mat_b):
+    scene = make_scene("path")
+    m = torch.from_numpy(mat_b).cuda().requires_grad_()
+    img = scene.render(m, res=(32, 32), spp=4)                   # seed defaults to 0
+    assert img.shape == (32, 32, 4) and img.dtype == torch.float32 and img.is_cuda
+    cam0 = scene.camera
+    scene.camera = type(cam0)(fov=0.3, origin=cam0.origin, target=cam0.target, up=cam0.up)   # changed after forward
+    img.sum().backward()
+    g1 = m.grad.clone(); m.grad = None
+    assert scene.camera.fov == pytest.approx(0.3)                # restored to the user's camera
+    scene.camera = cam0
+    scene.render(m, res=(32, 32), spp=4).sum().backward()
+    # backward used the camera snapshot of its own forward (render.py:216-222): same gradient up to atomics order
+    torch.testing.assert_close(g1, m.grad, rtol=1e-4, atol=1e-6)
+    with pytest.raises(AssertionError):
+        scene.render(torch.rand((8, 8, 3), device="cuda"), res=(8, 8), spp=1)
+    with pytest.raises(KeyError):
+        make_scene("bidirectional")
+
+
+def test_update_lights(mat_a):
+    scene = make_scene("direct")
+    m = torch.from_numpy(mat_a).cuda()
+    lit = scene.render(m, res=(32, 32), spp=4)
+    scene.update_lights([None, 0])
+    dark = scene.render(m, res=(32, 32), spp=4)
+    scene.update_lights([None, 20.0])
+    again = scene.render(m, res=(32, 32), spp=4)
+    assert lit[..., :3].max() > 1 and dark[..., :3].max() == 0 and torch.equal(lit, again)

@@ -1,0 +1,80 @@
+"""-m gpu: the acceleration structures (brute-force slot loop, BVH2 with LDS stack) against the
+oracle's brute-force Moeller-Trumbore, as LuisaCompute's Accel.trace_closest / trace_any."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import cbox_models
+from gpu_util import make_scene, random_rays, terrain_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+def check_closest(scene, S, rays, what):
+    ip, bt = scene.trace_closest(torch.from_numpy(rays).cuda())
+    ip, bt = ip.cpu().numpy(), bt.cpu().numpy()
+    rip, rbt = S.trace_closest(rays)
+    hit_g, hit_r = ip[:, 0] >= 0, rip[:, 0] >= 0
+    agree = hit_g == hit_r
+    print(f"[trace] {what}: hits {hit_r.mean():.3f}, hit/miss disagreements {(~agree).sum()} of {len(agree)}")
+    assert (~agree).mean() < 2e-4
+    both = hit_g & hit_r
+    same_prim = (ip[both] == rip[both]).all(axis=1)
+    assert (~same_prim).mean() < 2e-4          # exact ties on shared edges may pick the neighbour
+    ok = both.copy(); ok[both] = same_prim
+    np.testing.assert_allclose(bt[ok, 2], rbt[ok, 2], rtol=1e-5, atol=1e-6)      # t
+    np.testing.assert_allclose(bt[ok, :2], rbt[ok, :2], rtol=0, atol=2e-5)       # barycentrics
+
+
+@pytest.mark.parametrize("accel", ["brute", "bvh"])
+def test_cbox_closest_and_any(accel, cbox_arrays, cbox_oracle):
+    scene = make_scene("path", accel=accel)
+    assert scene.info()["accel"] == accel
+    rays = random_rays(100000, (-3, 0, -5.5), (2.5, 5.2, 6), seed=1)
+    check_closest(scene, cbox_oracle, rays, f"cbox/{accel}")
+    # occlusion rays of bounded length
+    rays[:, 3] = 1e-4; rays[:, 7] = np.random.default_rng(2).uniform(0.1, 6.0, rays.shape[0]).astype(np.float32)
+    occ = scene.trace_any(torch.from_numpy(rays).cuda()).cpu().numpy()
+    rocc = cbox_oracle.trace_any(rays)
+    assert (occ != rocc).mean() < 2e-4
+
+
+def test_bvh_equals_brute_on_the_gpu_exactly():
+    # same triangle test, only the culling differs: results must be identical bit for bit
+    a, b = make_scene("path", accel="brute"), make_scene("path", accel="bvh")
+    rays = torch.from_numpy(random_rays(200000, (-3, 0, -5.5), (2.5, 5.2, 6), seed=3)).cuda()
+    ipa, bta = a.trace_closest(rays); ipb, btb = b.trace_closest(rays)
+    same = (ipa == ipb).all(dim=1)
+    assert (~same).float().mean().item() < 1e-4
+    assert torch.equal(bta[same], btb[same])
+
+
+def test_terrain_bvh_matches_oracle_brute_force():
+    A = terrain_arrays(n=48)                       # 4.6k triangles: oracle brute force stays in seconds
+    scene = make_scene("path", arrays=A)
+    info = scene.info()
+    assert info["accel"] == "bvh" and info["bvh_nodes"] > 500
+    S = oracle.OracleScene.from_arrays(A)
+    rays = random_rays(30000, (-3, -0.5, -3), (3, 3.5, 3), seed=5)
+    check_closest(scene, S, rays, "terrain/bvh")
+    rays[:, 3] = 1e-4; rays[:, 7] = 2.5
+    occ = scene.trace_any(torch.from_numpy(rays).cuda()).cpu().numpy()
+    assert (occ != S.trace_any(rays)).mean() < 2e-4
+
+
+def test_large_bvh_any_is_consistent_with_closest():
+    # size-independent property at a scale the oracle cannot brute-force (131k triangles)
+    A = terrain_arrays(n=256)
+    scene = make_scene("path", arrays=A)
+    assert scene.info()["ntris"] == 2 * 256 * 256 + 2
+    rays = random_rays(500000, (-3, -0.5, -3), (3, 3.5, 3), seed=6)
+    tmax = np.random.default_rng(7).uniform(0.05, 5.0, rays.shape[0]).astype(np.float32)
+    r = torch.from_numpy(rays).cuda()
+    ip, bt = scene.trace_closest(r)
+    rays2 = rays.copy(); rays2[:, 7] = tmax
+    occ = scene.trace_any(torch.from_numpy(rays2).cuda())
+    t = bt[:, 2]; hit = ip[:, 0] >= 0
+    expect = hit & (t < torch.from_numpy(tmax).cuda())
+    margin = (t - torch.from_numpy(tmax).cuda()).abs() > 1e-4          # ignore hits right at tmax
+    assert ((occ != 0) == expect)[margin].all()

@@ -1,0 +1,108 @@
+// accel.h — closest-hit / any-hit queries (LuisaCompute Accel.trace_closest / trace_any).
+//  * BruteAccel: for scenes of a few dozen triangles (cbox: 32).  The slot loop is wave-uniform,
+//    so triangle data arrives through scalar loads into SGPRs and costs no VGPRs or LDS.
+//  * BvhAccel: BVH2 with a per-lane traversal stack in LDS laid out [entry][lane] (one bank per
+//    lane, conflict-free), 64-byte nodes and 48-byte triangles fetched with dwordx4 loads.
+// Both run the same two-sided Moeller-Trumbore test accepting tmin < t < tmax, so they return
+// the same hit (up to exact ties in t).
+#pragma once
+#include "scene.h"
+
+
+ZD bool tri_test(float4 a, float4 b, float4 c, f3 o, f3 d, float tmin, float tmax, float &t, float &u, float &v) {
+    f3 v0 = xyz(a), e1 = xyz(b), e2 = xyz(c);
+    f3 pv = cross(d, e2);
+    float det = dot(e1, pv);
+    float inv = rcp(det);
+    f3 tv = o - v0;
+    float uu = dot(tv, pv) * inv;
+    f3 qv = cross(tv, e1);
+    float vv = dot(d, qv) * inv;
+    float tt = dot(e2, qv) * inv;
+    bool ok = (det != 0.0f) & (uu >= 0.0f) & (uu <= 1.0f) & (vv >= 0.0f) & (uu + vv <= 1.0f) & (tt > tmin) & (tt < tmax);
+    t = tt; u = uu; v = vv;
+    return ok;
+}
+
+struct BruteAccel {
+    static constexpr bool kNeedsLds = false;
+    ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
+        Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
+        for (int s = 0; s < S.ntris; s++) {
+            float t, u, v;
+            bool ok = tri_test(S.isect[3 * s], S.isect[3 * s + 1], S.isect[3 * s + 2], o, d, tmin, h.t, t, u, v);
+            h.t = ok ? t : h.t; h.u = ok ? u : h.u; h.v = ok ? v : h.v; h.slot = ok ? s : h.slot;
+        }
+        return h;
+    }
+    ZD static bool any(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
+        bool occ = false;
+        for (int s = 0; s < S.ntris; s++) {
+            float t, u, v;
+            occ |= tri_test(S.isect[3 * s], S.isect[3 * s + 1], S.isect[3 * s + 2], o, d, tmin, tmax, t, u, v);
+        }
+        return occ;
+    }
+};
+
+// slab test against one child box; returns entry distance, or a value > tmax on a miss
+ZD float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float tmin, float tmax) {
+    float t0x = (lox - o.x) * inv.x, t1x = (hix - o.x) * inv.x;
+    float t0y = (loy - o.y) * inv.y, t1y = (hiy - o.y) * inv.y;
+    float t0z = (loz - o.z) * inv.z, t1z = (hiz - o.z) * inv.z;
+    // fminf/fmaxf drop NaNs (0 * inf on a slab boundary), which keeps the test conservative
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+    return (tn <= tf) ? tn : 3.0e38f;
+}
+
+struct BvhAccel {
+    static constexpr bool kNeedsLds = true;
+    // stack: this wave's LDS region, ZDR_BVH_STACK x 64 ints; entry e of lane l at stack[e * 64 + l]
+    template <bool ANY>
+    ZD static Hit traverse(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
+        Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
+        const int lane = threadIdx.x & 63;
+        f3 inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+        int sp = 0;
+        // work item: (id, cnt): cnt == 0 -> inner node id, cnt > 0 -> leaf [id, id + cnt)
+        int id = 0, cnt = (S.nnodes == 0) ? S.ntris : 0;
+        for (;;) {
+            if (cnt == 0) {
+                const float4 *n = S.nodes + 4 * (size_t)id;
+                float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                float e0 = box_entry(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, tmin, h.t);
+                float e1 = box_entry(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, tmin, h.t);
+                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                int k0 = __float_as_int(n3.z), k1 = __float_as_int(n3.w);
+                bool h0 = e0 < 2.0e38f, h1 = e1 < 2.0e38f;
+                if (h0 & h1) {
+                    bool swap = e1 < e0;                      // nearer child first
+                    int fid = swap ? c0 : c1, fk = swap ? k0 : k1;
+                    id = swap ? c1 : c0; cnt = swap ? k1 : k0;
+                    if (sp < ZDR_BVH_STACK) { stack[sp * 64 + lane] = (fid << 3) | fk; sp++; }
+                    continue;
+                } else if (h0) { id = c0; cnt = k0; continue; }
+                else if (h1) { id = c1; cnt = k1; continue; }
+            } else {
+                for (int s = id; s < id + cnt; s++) {
+                    float t, u, v;
+                    bool ok = tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, h.t, t, u, v);
+                    if (ok) { h.t = t; h.u = u; h.v = v; h.slot = s; }
+                }
+                if (ANY && h.slot >= 0) return h;
+            }
+            if (sp == 0) break;
+            sp--;
+            int e = stack[sp * 64 + lane];
+            id = e >> 3; cnt = e & 7;
+        }
+        return h;
+    }
+    ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
+        return traverse<false>(S, stack, o, d, tmin, tmax);
+    }
+    ZD static bool any(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
+        return traverse<true>(S, stack, o, d, tmin, tmax).slot >= 0;
+    }
+};

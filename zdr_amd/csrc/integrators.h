@@ -1,0 +1,255 @@
+// integrators.h — the three radiance estimators of the reference and their adjoints, written
+// for wave64: one lane owns one pixel and walks its samples in index order (the summation order
+// of integrator.py:15-29), but the path integrator runs as a flat state machine — each loop
+// trip every live lane advances its path by ONE bounce and finished lanes immediately start
+// their next sample, so short paths do not idle behind the longest path of the wave.
+#pragma once
+#include "accel.h"
+#include "internal.h"
+#include "microfacet.h"
+
+ZD float tent_warp1(float u) {                                   // camera.py:20-31, radius 1
+    return (u < 0.5f) ? (fsqrt(2.0f * u) - 1.0f) : (1.0f - fsqrt(2.0f - 2.0f * u));
+}
+
+// integrator.py:19-24 + camera.py:5-17
+template <int SK>
+ZD void pixel_ray(const RenderCfg &R, const SamplerCfg &C, Sampler &smp, int x, int y, f3 &o, f3 &d) {
+    f2 off = sampler_next2<SK>(C, smp);
+    if (R.use_tent) { off.x = tent_warp1(off.x) + 0.5f; off.y = tent_warp1(off.y) + 0.5f; }
+    float px = R.two_over_w * ((float)x + off.x) - 1.0f;
+    float py = R.two_over_h * ((float)y + off.y) - 1.0f;
+    py *= R.aspect;
+    px *= R.cam_tan; py *= R.cam_tan;
+    o = ld3(R.cam_o);
+    d = normalize((ld3(R.cam_right) * px - ld3(R.cam_upp) * py) + ld3(R.cam_fwd));
+}
+
+struct Counters { uint32_t c[8]; };
+enum { C_SAMPLES, C_CLOSEST, C_HITS, C_SHADOW, C_SHADED, C_EMIT_BSDF, C_NAN, C_UNUSED };
+#define COUNT(i) do { if (STATS) cnt.c[i]++; } while (0)
+
+ZD f3 clamp_radiance(f3 r) { return mk3(clampf(r.x, 0.0f, 100000.0f), clampf(r.y, 0.0f, 100000.0f), clampf(r.z, 0.0f, 100000.0f)); }
+ZD bool any_nonzero4(float4 g) { return (g.x != 0.0f) | (g.y != 0.0f) | (g.z != 0.0f) | (g.w != 0.0f); }
+ZD bool any_nan4(float4 g) { return (g.x != g.x) | (g.y != g.y) | (g.z != g.z) | (g.w != g.w); }
+ZD float4 brdf_grad(float cz_over_pi, float dfdr, f3 ct) {     // d(f cos)[ct] w.r.t. (d.rgb, r), App. A.6
+    return make_float4(ct.x * cz_over_pi, ct.y * cz_over_pi, ct.z * cz_over_pi, (ct.x + ct.y + ct.z) * dfdr);
+}
+
+// ---------------------------------------------------------------------------- collocated
+// collocated.py:11-31 / 35-57: L = brdf(wo, wo) / t^2
+template <class A, bool BWD, bool STATS>
+ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io, int *lds, f3 o, f3 d, f3 le_grad, Counters &cnt) {
+    COUNT(C_CLOSEST);
+    Hit h = A::closest(S, lds, o, d, 0.0f, 1e30f);
+    if (h.slot < 0) return mk3(0.0f);
+    COUNT(C_HITS);
+    Interaction it = surface_interact(S, h);
+    if (dot(-d, it.ng) < 1e-4f || dot(-d, it.ns) < 1e-4f) return mk3(0.0f);
+    float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
+    COUNT(C_SHADED);
+    Onb onb = make_onb(it.ns);
+    f3 wo = to_local(onb, -d);
+    GgxTerms g = ggx_terms(wo, wo, m.w);
+    float inv_t = rcp(h.t), li = inv_t * inv_t;
+    if (BWD) {
+        float4 gr = brdf_grad(wo.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, m.w), le_grad * li);
+        if (!any_nan4(gr)) write_bsdf_grad(io.d_material, it.uv, gr, R.tex_h, R.tex_w);
+    }
+    return ggx_brdf_from(g, wo, mk3(m.x, m.y, m.z)) * li;
+}
+
+// -------------------------------------------------------------------------------- direct
+// direct.py:21-85 (forward) / 89-167 (adjoint; gradient written once at the primary uv, App. B-11)
+template <int SK, class A, bool BWD, bool STATS>
+ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
+                    Sampler &smp, f3 o, f3 d, f3 le_grad, Counters &cnt) {
+    COUNT(C_CLOSEST);
+    Hit h = A::closest(S, lds, o, d, 0.0f, 1e30f);
+    if (h.slot < 0) return mk3(0.0f);
+    COUNT(C_HITS);
+    Interaction it = surface_interact(S, h);
+    if (dot(-d, it.ng) < 1e-4f || dot(-d, it.ns) < 1e-4f) return mk3(0.0f);
+    if (it.inst > 0) return ld3(S.emission + 3 * it.inst);                        // direct.py:30-32
+    float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
+    f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
+    COUNT(C_SHADED);
+    float4 mat_grad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    f3 radiance = mk3(0.0f);
+    float u_pick = sampler_next<SK>(C, smp), u_prim = sampler_next<SK>(C, smp);
+    f2 u_pt = sampler_next2<SK>(C, smp);
+    LightSample light = sample_light(S, it.p, u_pick, u_prim, u_pt);
+    COUNT(C_SHADOW);
+    bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
+    Onb onb = make_onb(it.ns);
+    f3 wo = to_local(onb, -d);
+    f3 wil = to_local(onb, light.wi);
+    if (!occluded && wil.z > 0.0f) {                                              // direct.py:49
+        GgxTerms g = ggx_terms(wo, wil, roughness);
+        f3 bsdf = ggx_brdf_from(g, wil, diffuse);
+        float pdf_bsdf = ggx_pdf_from(g, wo, wil);
+        float mis = balanced_heuristic(light.pdf, pdf_bsdf);
+        float inv_dn = rcp(fmaxf(light.pdf, 1e-4f));
+        radiance = radiance + ((bsdf * mis) * light.eval) * inv_dn;
+        if (BWD) {
+            f3 W = (light.eval * mis) * inv_dn;
+            float4 gr = brdf_grad(wil.z * ZDR_INV_PI, ggx_dfdr_from(g, wil, roughness), W * le_grad);
+            mat_grad.x += gr.x; mat_grad.y += gr.y; mat_grad.z += gr.z; mat_grad.w += gr.w;
+        }
+    }
+    // use_MIS = True (direct.py:14): one BSDF sample, emitter lookup only
+    float u_lobe = sampler_next<SK>(C, smp);
+    f2 u_dir = sampler_next2<SK>(C, smp);
+    f3 wi_local = ggx_sample(wo, roughness, u_lobe, u_dir);
+    f3 wi = to_world(onb, wi_local);
+    if (!(dot(wi, it.ng) < 1e-4f || wi_local.z < 1e-4f)) {
+        f3 o2 = offset_ray_origin(it.p, it.ng);
+        COUNT(C_CLOSEST);
+        Hit h2 = A::closest(S, lds, o2, wi, 0.0f, 1e30f);
+        if (h2.slot >= 0) {
+            COUNT(C_HITS);
+            Interaction it2 = surface_interact(S, h2);
+            if (!(dot(-wi, it2.ng) < 1e-4f || dot(-wi, it2.ns) < 1e-4f)) {
+                f3 em = ld3(S.emission + 3 * it2.inst);
+                if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {
+                    float pdf_light = sample_light_pdf(S, it.p, it2.inst, h2.slot, it2.p);   // origin = it.p (direct.py:66)
+                    GgxTerms g = ggx_terms(wo, wi_local, roughness);
+                    float pdf_bsdf = ggx_pdf_from(g, wo, wi_local);
+                    float mis = balanced_heuristic(pdf_bsdf, pdf_light);
+                    float inv_p = rcp(pdf_bsdf);
+                    f3 beta = ggx_brdf_from(g, wi_local, diffuse) * inv_p;
+                    COUNT(C_EMIT_BSDF);
+                    radiance = radiance + (beta * mis) * em;
+                    if (BWD) {
+                        float4 gr = brdf_grad(wi_local.z * ZDR_INV_PI, ggx_dfdr_from(g, wi_local, roughness), (em * (mis * inv_p)) * le_grad);
+                        mat_grad.x += gr.x; mat_grad.y += gr.y; mat_grad.z += gr.z; mat_grad.w += gr.w;
+                    }
+                }
+            }
+        }
+    }
+    if (BWD) {
+        if (any_nonzero4(mat_grad) && !any_nan4(mat_grad)) write_bsdf_grad(io.d_material, it.uv, mat_grad, R.tex_h, R.tex_w);
+    }
+    return radiance;
+}
+
+// ---------------------------------------------------------------------------------- path
+// One shaded vertex as the adjoint sweep needs it.  With the per-event
+// derivative factors evaluated during the walk, the sweep is a handful of FMAs per vertex:
+//   grad_k = d f^L_k [ bW g ] + d f_k [ bpq Li_{k+1} g ],   Li_k = fLW + T Li_{k+1}
+struct PathVertex {
+    f2 uv;
+    f3 bW;  float cL, dfLdr;     // beta_k * W_k;  wiL.z/pi;  d(f^L cos)/dr      (0 when NEE rejected)
+    f3 bpq; float c, dfdr;       // beta_k/(p_k q_k);  wi.z/pi;  d(f cos)/dr     (0 when the path stops here)
+    f3 T, fLW;                   // f_k/(p_k q_k);  f^L_k * W_k
+};
+
+// Per-lane path state of the flat loop.
+struct PathState {
+    f3 o, d, beta, L;
+    float pdf_bsdf;
+    int depth;
+    Sampler smp;
+};
+
+// Advance one live path by one bounce (prb.py:23-87 is the body of `for depth in range(max_depth)`).
+// Returns true when the path has terminated.  BWD: appends to rec[nrec] and sets term_Li.
+template <int SK, class A, bool BWD, bool STATS>
+ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
+                    PathState &ps, PathVertex *rec, int &nrec, f3 &term_Li, Counters &cnt) {
+    COUNT(C_CLOSEST);
+    Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+    if (h.slot < 0) return true;                                                  // prb.py:26-32, env_count == 0
+    COUNT(C_HITS);
+    Interaction it = surface_interact(S, h);
+    if (dot(-ps.d, it.ng) < 1e-4f || dot(-ps.d, it.ns) < 1e-4f) return true;      // prb.py:35-36
+    f3 em = ld3(S.emission + 3 * it.inst);
+    if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {                              // prb.py:39-44
+        float pdf_light = sample_light_pdf(S, ps.o, it.inst, h.slot, it.p);
+        float mis = balanced_heuristic(ps.pdf_bsdf, pdf_light);
+        ps.L = ps.L + (ps.beta * mis) * em;
+        if (BWD) term_Li = em * mis;
+        if (STATS && ps.depth > 0) cnt.c[C_EMIT_BSDF]++;
+        return true;
+    }
+    if (it.inst > 0) return true;                                                 // prb.py:45-46
+    float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
+    f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
+    COUNT(C_SHADED);
+    PathVertex pv;
+    if (BWD) {
+        pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
+        pv.T = mk3(0.0f); pv.fLW = mk3(0.0f);
+    }
+    Onb onb = make_onb(it.ns);
+    f3 wo = to_local(onb, -ps.d);
+    // next-event estimation (prb.py:57-66)
+    float u_pick = sampler_next<SK>(C, ps.smp), u_prim = sampler_next<SK>(C, ps.smp);
+    f2 u_pt = sampler_next2<SK>(C, ps.smp);
+    LightSample light = sample_light(S, it.p, u_pick, u_prim, u_pt);
+    COUNT(C_SHADOW);
+    bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
+    f3 wil = to_local(onb, light.wi);
+    if (!occluded && wil.z >= 1e-4f) {
+        GgxTerms g = ggx_terms(wo, wil, roughness);
+        f3 bsdf = ggx_brdf_from(g, wil, diffuse);
+        float pb = ggx_pdf_from(g, wo, wil);
+        float mis = balanced_heuristic(light.pdf, pb);
+        float inv_dn = rcp(fmaxf(light.pdf, 1e-4f));
+        ps.L = ps.L + (((ps.beta * bsdf) * mis) * light.eval) * inv_dn;
+        if (BWD) {
+            f3 W = (light.eval * mis) * inv_dn;
+            pv.bW = ps.beta * W; pv.cL = wil.z * ZDR_INV_PI; pv.dfLdr = ggx_dfdr_from(g, wil, roughness);
+            pv.fLW = bsdf * W;
+        }
+    }
+    // BSDF sampling (prb.py:69-76)
+    float u_lobe = sampler_next<SK>(C, ps.smp);
+    f2 u_dir = sampler_next2<SK>(C, ps.smp);
+    f3 wi_local = ggx_sample(wo, roughness, u_lobe, u_dir);
+    GgxTerms g = ggx_terms(wo, wi_local, roughness);
+    ps.pdf_bsdf = ggx_pdf_from(g, wo, wi_local);
+    f3 wi = to_world(onb, wi_local);
+    bool stop = (dot(wi, it.ng) < 1e-4f) || (wi_local.z < 1e-4f);                 // prb.py:73-74
+    f3 beta_in = ps.beta;
+    float q = 1.0f;
+    if (!stop) {
+        ps.o = offset_ray_origin(it.p, it.ng); ps.d = wi;
+        f3 f = ggx_brdf_from(g, wi_local, diffuse);
+        float inv_p = rcp(ps.pdf_bsdf);
+        ps.beta = ps.beta * (f * inv_p);
+        if (ps.depth >= R.rr_depth) {                                             // prb.py:79-87
+            float l = 0.212671f * ps.beta.x + 0.715160f * ps.beta.y + 0.072169f * ps.beta.z;
+            if (l == 0.0f) stop = true;
+            else {
+                q = fmaxf(l, 0.05f);
+                float r = sampler_next<SK>(C, ps.smp);
+                if (r >= q) stop = true;
+                else ps.beta = ps.beta * rcp(q);
+            }
+        }
+        if (BWD && !stop) {
+            float inv_pq = inv_p * rcp(q);
+            pv.bpq = beta_in * inv_pq; pv.c = wi_local.z * ZDR_INV_PI; pv.dfdr = ggx_dfdr_from(g, wi_local, roughness);
+            pv.T = f * inv_pq;
+        }
+    }
+    if (BWD) { rec[nrec] = pv; nrec++; }
+    ps.depth++;
+    if (ps.depth >= R.max_depth) stop = true;
+    return stop;
+}
+
+// Adjoint sweep over the recorded vertices, last to first (prb.py:105-187, corrected weight App. B-3)
+ZD void path_sweep(const RenderCfg &R, const KernelIO &io, const PathVertex *rec, int nrec, f3 Li, f3 le_grad) {
+    for (int k = nrec - 1; k >= 0; k--) {
+        PathVertex v = rec[k];
+        f3 ctL = v.bW * le_grad;
+        f3 ct = (v.bpq * Li) * le_grad;
+        float4 a = brdf_grad(v.cL, v.dfLdr, ctL), b = brdf_grad(v.c, v.dfdr, ct);
+        float4 g = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        Li = v.fLW + v.T * Li;
+        if (any_nonzero4(g) && !any_nan4(g)) write_bsdf_grad(io.d_material, v.uv, g, R.tex_h, R.tex_w);   // prb.py:178-187
+    }
+}

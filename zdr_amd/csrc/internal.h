@@ -1,0 +1,39 @@
+// internal.h — structures shared by the host side (zdr_api.cpp) and the kernels (zdr_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sampler.h"
+#include "scene.h"
+
+#define ZDR_MAX_RECORDED_DEPTH 16     // prb.py:15 max_depth; vertex records kept per path in backward
+
+// Wave-uniform launch configuration (kernel argument, lives in SGPRs).
+struct RenderCfg {
+    int32_t width, height;
+    int32_t x0, y0, x1, y1;
+    uint32_t sample_begin, sample_end;
+    uint32_t chunk;                   // samples per wave: chunk c covers [begin + c*chunk, ...)
+    int32_t nchunks, tiles_x, tiles_y;
+    int32_t use_tent, max_depth, rr_depth;
+    int32_t tex_h, tex_w;
+    float two_over_w, two_over_h, aspect;      // integrator.py:22-23
+    float inv_spp;                             // 1 / spp as computed by IEEE division
+    float alpha;                               // (sample_end - sample_begin) / spp
+    float cam_o[3], cam_fwd[3], cam_right[3], cam_upp[3], cam_tan;   // camera.py:12-15
+};
+
+struct KernelIO {
+    const float4 *material;           // (tex_h, tex_w) float4
+    float4 *image;                    // (H, W) float4
+    float4 *partial;                  // nchunks x (H*W) float4 scratch when nchunks > 1
+    const float4 *d_image;            // backward: cotangent
+    float *d_material;                // backward: accumulated with float atomics
+    unsigned long long *counters;     // stats variant: 8 counters
+};
+
+int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
+                      int integrator, int accel_is_bvh, int backward, int stats, hipStream_t stream);
+int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *rays, uint32_t n,
+                     int32_t *out_i, float *out_f, hipStream_t stream);
+int zdr_launch_sampler_dump(const SamplerCfg &C, const int32_t *queries, uint32_t n, int32_t nvert,
+                            int32_t rr_depth, float *out, hipStream_t stream);

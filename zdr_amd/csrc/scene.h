@@ -1,0 +1,163 @@
+// scene.h — device-side scene: what LuisaCompute's Accel + bindless heap held for the reference
+// (render.py:73-128).  Instances are flattened to world space at build time; triangles live in
+// "slot" order (the BVH's leaf order, or input order for the brute-force accel).
+#pragma once
+#include "vecmath.h"
+
+#define ZDR_BVH_STACK 48   // per-lane traversal stack entries; the builder bounds the tree depth below it
+
+// Per-slot records, 16-byte aligned so a record is fetched with dwordx4 loads:
+//   isect[3*slot + {0,1,2}] = {v0.xyz,0} {e1.xyz,0} {e2.xyz,0}         (48 B, traversal)
+//   shade[8*slot + ...]     = one 128-byte line:                       (surface_interact, lights)
+//     r0 {p0.xyz, uv0.x} r1 {p1.xyz, uv0.y} r2 {p2.xyz, uv1.x}
+//     r3 {n0.xyz, uv1.y} r4 {n1.xyz, uv2.x} r5 {n2.xyz, uv2.y}   n_i = inverse-transpose(M) * vn_i
+//     r6 {ng.xyz, area}                                          ng = normalize(cross(p1-p0, p2-p0))
+//     r7 {bits(inst), bits(prim), 0, 0}
+// BVH2 node (64 B): {lo0.xyz, hi0.x} {hi0.yz, lo1.xy} {lo1.z, hi1.xyz} {child0, child1, cnt0, cnt1}
+//   cnt == 0: child is a node index; cnt > 0: child is the first slot of a leaf of cnt triangles.
+struct DScene {
+    const float4 *isect;
+    const float4 *shade;
+    const float4 *nodes;
+    const float *emission;          // ninst x 3   (heap slot 23333)
+    const int32_t *light_insts;     // ninst       (heap slot 23334)
+    const int32_t *inst_tri_begin;  // ninst + 1   (heap slot 23335 holds the counts)
+    const int32_t *slot_of_tri;     // input triangle index -> slot
+    int32_t ntris, ninst, light_count, nnodes;
+};
+
+struct Hit { int slot; float u, v, t; };   // slot < 0: miss (LuisaCompute Hit{inst, prim, bary, ray_t})
+
+struct Interaction {                       // interaction.py:6
+    f3 p; f2 uv; f3 ns, ng; int inst, prim;
+};
+
+ZD f3 xyz(float4 a) { return mk3(a.x, a.y, a.z); }
+
+ZD Interaction surface_interact(const DScene &S, const Hit &h) {   // interaction.py:9-30
+    const float4 *r = S.shade + 8 * (size_t)h.slot;
+    float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
+    float w0 = 1.0f - h.u - h.v, w1 = h.u, w2 = h.v;               // Hit::interpolate
+    Interaction it;
+    it.p = xyz(r0) * w0 + xyz(r1) * w1 + xyz(r2) * w2;
+    it.uv.x = w0 * r0.w + w1 * r2.w + w2 * r4.w;
+    it.uv.y = w0 * r1.w + w1 * r3.w + w2 * r5.w;
+    it.ns = normalize(xyz(r3) * w0 + xyz(r4) * w1 + xyz(r5) * w2);
+    it.ng = xyz(r6);
+    it.inst = __float_as_int(r7.x); it.prim = __float_as_int(r7.y);
+    return it;
+}
+
+// read_bsdf (interaction.py:47-60): bilinear, CLAMP addressing, texel (x, y) at x + tex_w * y
+struct TexFoot { int i00, i01, i10, i11; float ox, oy; };   // element indices (x4 floats) of the 4 texels
+
+ZD TexFoot tex_footprint(f2 uv, int tex_h, int tex_w) {
+    float px = uv.x * (float)(tex_w - 1), py = (1.0f - uv.y) * (float)(tex_h - 1);
+    int ix = (int)px, iy = (int)py;
+    TexFoot f;
+    f.ox = px - (float)ix; f.oy = py - (float)iy;
+    int x0 = clampi(ix, 0, tex_w - 1), x1 = clampi(ix + 1, 0, tex_w - 1);
+    int y0 = clampi(iy, 0, tex_h - 1), y1 = clampi(iy + 1, 0, tex_h - 1);
+    f.i00 = x0 + tex_w * y0; f.i01 = x0 + tex_w * y1; f.i10 = x1 + tex_w * y0; f.i11 = x1 + tex_w * y1;
+    return f;
+}
+
+ZD float4 read_bsdf(const float4 *__restrict__ mat, f2 uv, int tex_h, int tex_w) {
+    TexFoot f = tex_footprint(uv, tex_h, tex_w);
+    float4 c00 = mat[f.i00], c01 = mat[f.i01], c10 = mat[f.i10], c11 = mat[f.i11];
+    float4 r;
+    r.x = lerpf(lerpf(c00.x, c01.x, f.oy), lerpf(c10.x, c11.x, f.oy), f.ox);
+    r.y = lerpf(lerpf(c00.y, c01.y, f.oy), lerpf(c10.y, c11.y, f.oy), f.ox);
+    r.z = lerpf(lerpf(c00.z, c01.z, f.oy), lerpf(c10.z, c11.z, f.oy), f.ox);
+    r.w = lerpf(lerpf(c00.w, c01.w, f.oy), lerpf(c10.w, c11.w, f.oy), f.ox);
+    return r;
+}
+
+// write_bsdf_grad (interaction.py:63-89): 4 texels x 4 float atomics (global_atomic_add_f32)
+ZD void write_bsdf_grad(float *__restrict__ dmat, f2 uv, float4 g, int tex_h, int tex_w) {
+    TexFoot f = tex_footprint(uv, tex_h, tex_w);
+    float k00 = (1.0f - f.ox) * (1.0f - f.oy), k01 = (1.0f - f.ox) * f.oy;
+    float k10 = f.ox * (1.0f - f.oy), k11 = f.ox * f.oy;
+    const int idx[4] = {f.i00, f.i01, f.i10, f.i11};
+    const float k[4] = {k00, k01, k10, k11};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float *p = dmat + 4 * (size_t)idx[j];
+        unsafeAtomicAdd(p + 0, k[j] * g.x); unsafeAtomicAdd(p + 1, k[j] * g.y);
+        unsafeAtomicAdd(p + 2, k[j] * g.z); unsafeAtomicAdd(p + 3, k[j] * g.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------ lights
+struct LightSample { f3 wi; float dist, pdf; f3 eval; };       // light.py:11
+
+ZD f3 sample_uniform_triangle(f2 u) {                           // light.py:16-20
+    f2 uv;
+    if (u.x < u.y) { uv.x = 0.5f * u.x; uv.y = -0.5f * u.x + u.y; }
+    else { uv.x = -0.5f * u.y + u.x; uv.y = 0.5f * u.y; }
+    return mk3(uv.x, uv.y, 1.0f - uv.x - uv.y);
+}
+
+// pdf = d^2 / (n T area cos_light)  (light.py:69-73, 105-110); ng and area are precomputed per slot
+ZD float light_pdf(f3 origin, f3 p, f3 ln, float area, int n_times_T, f3 &wi, float &cos_light, float &sqr_dist) {
+    f3 dp = p - origin;
+    wi = normalize(dp);
+    cos_light = -dot(ln, wi);
+    sqr_dist = dot(dp, dp);
+    return sqr_dist * rcp((float)n_times_T * area * cos_light);
+}
+
+// sample_light (light.py:23-81) for mesh lights; consumes next(), next(), next2f()
+ZD LightSample sample_light(const DScene &S, f3 origin, float u_pick, float u_prim, f2 u_pt) {
+    LightSample L;
+    int n = S.light_count;
+    if (n <= 0) {  // the reference would index out of bounds; contribute nothing
+        L.wi = mk3(0.0f, 0.0f, 1.0f); L.dist = 0.0f; L.pdf = 1.0f; L.eval = mk3(0.0f);
+        return L;
+    }
+    int idx = clampi((int)(u_pick * (float)n), 0, n - 1);
+    int inst = S.light_insts[idx];
+    int b = S.inst_tri_begin[inst];
+    int T = S.inst_tri_begin[inst + 1] - b;
+    int prim = clampi((int)(u_prim * (float)T), 0, T - 1);
+    const float4 *r = S.shade + 8 * (size_t)S.slot_of_tri[b + prim];
+    float4 r0 = r[0], r1 = r[1], r2 = r[2], r6 = r[6];
+    f3 abc = sample_uniform_triangle(u_pt);
+    f3 p = xyz(r0) * abc.x + xyz(r1) * abc.y + xyz(r2) * abc.z;
+    float cos_light, sqr_dist;
+    L.pdf = light_pdf(origin, p, xyz(r6), r6.w, n * T, L.wi, cos_light, sqr_dist);
+    L.dist = 0.9999f * fsqrt(sqr_dist);
+    f3 e = ld3(S.emission + 3 * inst);
+    L.eval = (cos_light > 1e-4f) ? e : mk3(0.0f);
+    return L;
+}
+
+// sample_light_pdf (light.py:84-111): pdf of having light-sampled point p on (inst, slot)
+ZD float sample_light_pdf(const DScene &S, f3 origin, int inst, int slot, f3 p) {
+    float4 r6 = S.shade[8 * (size_t)slot + 6];
+    int T = S.inst_tri_begin[inst + 1] - S.inst_tri_begin[inst];
+    f3 wi; float c, d2;
+    return light_pdf(origin, p, xyz(r6), r6.w, S.light_count * T, wi, c, d2);
+}
+
+ZD float balanced_heuristic(float a, float b) { return a * rcp(fmaxf(a + b, 1e-4f)); }   // prb.py:12-13
+
+// LuisaCompute offset_ray_origin (Waechter & Binder, RT Gems ch.6) — prb.py:75, direct.py:64
+ZD float offset1(float p, float n) {
+    int of_i = (int)(256.0f * n);
+    float p_i = __int_as_float(__float_as_int(p) + ((p < 0.0f) ? -of_i : of_i));
+    return (fabsf(p) < (1.0f / 32.0f)) ? p + (1.0f / 65536.0f) * n : p_i;
+}
+ZD f3 offset_ray_origin(f3 p, f3 n) { return mk3(offset1(p.x, n.x), offset1(p.y, n.y), offset1(p.z, n.z)); }
+
+// --------------------------------------------------------------------------------------- onb
+struct Onb { f3 tangent, binormal, normal; };                   // onb.py:7
+ZD Onb make_onb(f3 n) {                                         // onb.py:21-28
+    Onb o;
+    o.binormal = normalize((fabsf(n.x) > fabsf(n.z)) ? mk3(-n.y, n.x, 0.0f) : mk3(0.0f, -n.z, n.y));
+    o.tangent = normalize(cross(o.binormal, n));
+    o.normal = n;
+    return o;
+}
+ZD f3 to_world(const Onb &o, f3 v) { return v.x * o.tangent + v.y * o.binormal + v.z * o.normal; }
+ZD f3 to_local(const Onb &o, f3 v) { return mk3(dot(v, o.tangent), dot(v, o.binormal), dot(v, o.normal)); }

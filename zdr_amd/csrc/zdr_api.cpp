@@ -1,0 +1,465 @@
+// zdr_api.cpp — host side of libzdr_hip.so: scene assembly (what LuisaCompute's Accel / heap did
+// for render.py:73-128), a binned-SAH BVH2 builder, launch configuration, and the C-ABI of
+// include/zdr.h.  Compiled with hipcc -ffp-contract=off: per-triangle constants (edges, geometric
+// normal, area, camera frame) are then plain IEEE float32 and reproducible on any host.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+#include "zdr.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ZDR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" const char *zdr_version(void) { return ZDR_VERSION_STRING; }
+extern "C" const char *zdr_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------ host vec3
+struct h3 { float x, y, z; };
+static inline h3 H3(float x, float y, float z) { return {x, y, z}; }
+static inline h3 hsub(h3 a, h3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline h3 hcross(h3 a, h3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline float hdot(h3 a, h3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline h3 hscale(h3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static inline h3 hnormalize(h3 a) { return hscale(a, 1.0f / sqrtf(hdot(a, a))); }
+static inline h3 xform_point(const float *m, h3 v) {      // (M * float4(v,1)).xyz, interaction.py:19-21
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3], m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7], m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11]};
+}
+static void normal_matrix(const float *m, float *n) {      // inverse(transpose(M3x3)), interaction.py:28
+    float a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    float c10 = c * h - b * i, c11 = a * i - c * g, c12 = b * g - a * h;
+    float c20 = b * f - c * e, c21 = c * d - a * f, c22 = a * e - b * d;
+    float inv = 1.0f / (a * c00 + b * c01 + c * c02);
+    n[0] = c00 * inv; n[1] = c01 * inv; n[2] = c02 * inv; n[3] = c10 * inv; n[4] = c11 * inv; n[5] = c12 * inv;
+    n[6] = c20 * inv; n[7] = c21 * inv; n[8] = c22 * inv;
+}
+
+// ------------------------------------------------------------------------------ BVH builder
+// Binned SAH (16 bins, 3 axes), leaves of <= 4 triangles, depth bounded by the traversal stack.
+struct BNode { float lo[3], hi[3]; int left, right, first, count; };
+struct Prim { float lo[3], hi[3], c[3]; int tri; };
+
+struct BvhBuilder {
+    std::vector<Prim> prims;
+    std::vector<BNode> nodes;
+    int max_depth = 0;
+    static constexpr int kLeaf = 4, kBins = 16, kDepthLimit = ZDR_BVH_STACK - 2;
+
+    static void grow(float *lo, float *hi, const float *plo, const float *phi) {
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], plo[k]); hi[k] = std::max(hi[k], phi[k]); }
+    }
+    static float area(const float *lo, const float *hi) {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+    int build(int b, int e, int depth) {
+        int id = (int)nodes.size();
+        nodes.push_back(BNode());
+        max_depth = std::max(max_depth, depth);
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+        float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
+        for (int i = b; i < e; i++) { grow(lo, hi, prims[i].lo, prims[i].hi); grow(clo, chi, prims[i].c, prims[i].c); }
+        BNode nd; memcpy(nd.lo, lo, 12); memcpy(nd.hi, hi, 12); nd.left = nd.right = -1; nd.first = b; nd.count = e - b;
+        int n = e - b;
+        if (n <= kLeaf) { nodes[id] = nd; return id; }
+        int mid = -1;
+        // levels still needed if we split at the median from here on
+        int need = 0; for (int m = (n + kLeaf - 1) / kLeaf; m > 1; m = (m + 1) / 2) need++;
+        bool force_median = depth + need + 1 >= kDepthLimit;
+        if (!force_median) {
+            float best = 3e38f; int best_axis = -1, best_bin = -1;
+            for (int ax = 0; ax < 3; ax++) {
+                float ext = chi[ax] - clo[ax];
+                if (!(ext > 0.0f)) continue;
+                float blo[kBins][3], bhi[kBins][3]; int bc[kBins];
+                for (int k = 0; k < kBins; k++) { bc[k] = 0; for (int j = 0; j < 3; j++) { blo[k][j] = 3e38f; bhi[k][j] = -3e38f; } }
+                float scale = (float)kBins / ext;
+                for (int i = b; i < e; i++) {
+                    int k = std::min(kBins - 1, std::max(0, (int)((prims[i].c[ax] - clo[ax]) * scale)));
+                    bc[k]++; grow(blo[k], bhi[k], prims[i].lo, prims[i].hi);
+                }
+                float rlo[kBins][3], rhi[kBins][3]; int rc[kBins];
+                float alo[3] = {3e38f, 3e38f, 3e38f}, ahi[3] = {-3e38f, -3e38f, -3e38f}; int ac = 0;
+                for (int k = kBins - 1; k > 0; k--) { if (bc[k]) grow(alo, ahi, blo[k], bhi[k]); ac += bc[k]; memcpy(rlo[k], alo, 12); memcpy(rhi[k], ahi, 12); rc[k] = ac; }
+                float llo[3] = {3e38f, 3e38f, 3e38f}, lhi[3] = {-3e38f, -3e38f, -3e38f}; int lc = 0;
+                for (int k = 0; k < kBins - 1; k++) {
+                    if (bc[k]) grow(llo, lhi, blo[k], bhi[k]); lc += bc[k];
+                    if (lc == 0 || rc[k + 1] == 0) continue;
+                    float cost = area(llo, lhi) * (float)lc + area(rlo[k + 1], rhi[k + 1]) * (float)rc[k + 1];
+                    if (cost < best) { best = cost; best_axis = ax; best_bin = k; }
+                }
+            }
+            if (best_axis >= 0) {
+                float ext = chi[best_axis] - clo[best_axis], scale = (float)kBins / ext;
+                auto it = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim &p) {
+                    int k = std::min(kBins - 1, std::max(0, (int)((p.c[best_axis] - clo[best_axis]) * scale)));
+                    return k <= best_bin; });
+                mid = (int)(it - prims.begin());
+            }
+        }
+        if (mid <= b || mid >= e) {   // median split along the widest centroid axis
+            int ax = 0; float w = chi[0] - clo[0];
+            for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > w) { w = chi[k] - clo[k]; ax = k; }
+            mid = b + n / 2;
+            std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e, [ax](const Prim &p, const Prim &q) { return p.c[ax] < q.c[ax]; });
+        }
+        int l = build(b, mid, depth + 1);
+        int r = build(mid, e, depth + 1);
+        nd.left = l; nd.right = r; nd.count = 0;
+        nodes[id] = nd;
+        return id;
+    }
+};
+
+// ----------------------------------------------------------------------------------- scene
+struct zdr_scene {
+    int device = 0;
+    int accel_is_bvh = 0;
+    uint32_t ntris = 0, nverts = 0, ninst = 0;
+    uint32_t bvh_nodes = 0, bvh_depth = 0;
+    std::vector<int32_t> inst_tri_begin;
+    std::vector<float> emission;
+    float4 *d_isect = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
+    float *d_emission = nullptr;
+    int32_t *d_light_insts = nullptr, *d_inst_tri_begin = nullptr, *d_slot_of_tri = nullptr;
+    uint32_t *d_pmj = nullptr; uint16_t *d_bn = nullptr; SamplerTables tab{};
+    float4 *d_partial = nullptr; size_t partial_bytes = 0;
+    unsigned long long *d_counters = nullptr;
+    uint64_t device_bytes = 0;
+    DScene ds{};
+};
+
+template <class T>
+static hipError_t upload(T **dst, const void *src, size_t bytes, uint64_t *acc) {
+    hipError_t e = hipMalloc((void **)dst, std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) return e;
+    if (acc) *acc += bytes;
+    return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+}
+
+static void light_list(const std::vector<float> &em, uint32_t ninst, std::vector<int32_t> &out, int &count) {
+    out.assign(ninst, 0); count = 0;     // render.py:89-90,118-121,146-148
+    for (uint32_t i = 0; i < ninst; i++)
+        if (em[3 * i] > 0.0f || em[3 * i + 1] > 0.0f || em[3 * i + 2] > 0.0f) out[count++] = (int32_t)i;
+}
+
+extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int32_t *tris, uint32_t ntris,
+                                const int32_t *inst_tri_begin, const float *inst_xform, const float *inst_emission,
+                                uint32_t ninst, int device, int accel, zdr_scene **out) {
+    if (!verts8 || !tris || !inst_tri_begin || !inst_emission || !out) return fail(ZDR_E_INVALID, "null argument");
+    if (ntris == 0 || nverts == 0 || ninst == 0) return fail(ZDR_E_INVALID, "empty scene");
+    if (ninst > 10000) return fail(ZDR_E_INVALID, "exceeding maximum number of mesh instances");   // render.py:114-115
+    if (ntris >= (1u << 28)) return fail(ZDR_E_UNSUPPORTED, "too many triangles");
+    if (inst_tri_begin[0] != 0 || (uint32_t)inst_tri_begin[ninst] != ntris) return fail(ZDR_E_INVALID, "inst_tri_begin must span [0, ntris]");
+    for (uint32_t i = 0; i < ninst; i++) if (inst_tri_begin[i + 1] < inst_tri_begin[i]) return fail(ZDR_E_INVALID, "inst_tri_begin must be non-decreasing");
+    for (size_t i = 0; i < (size_t)ntris * 3; i++) if (tris[i] < 0 || (uint32_t)tris[i] >= nverts) return fail(ZDR_E_INVALID, "triangle index out of range");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ZDR_E_INVALID, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+
+    zdr_scene *s = new zdr_scene();
+    s->device = device; s->ntris = ntris; s->nverts = nverts; s->ninst = ninst;
+    s->inst_tri_begin.assign(inst_tri_begin, inst_tri_begin + ninst + 1);
+    s->emission.assign(inst_emission, inst_emission + 3 * (size_t)ninst);
+
+    // world-space per-triangle records in input order
+    struct TriRec { h3 p[3], n[3]; float uv[3][2]; h3 ng; float area; int inst, prim; };
+    std::vector<TriRec> rec(ntris);
+    static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float slo[3] = {3e38f, 3e38f, 3e38f}, shi[3] = {-3e38f, -3e38f, -3e38f};
+    for (uint32_t i = 0; i < ninst; i++) {
+        const float *m = inst_xform ? inst_xform + 16 * (size_t)i : ident;
+        float nm[9]; normal_matrix(m, nm);
+        for (int t = inst_tri_begin[i]; t < inst_tri_begin[i + 1]; t++) {
+            TriRec &r = rec[t];
+            for (int k = 0; k < 3; k++) {
+                const float *v = verts8 + 8 * (size_t)tris[3 * (size_t)t + k];
+                r.p[k] = xform_point(m, H3(v[0], v[1], v[2]));
+                r.uv[k][0] = v[3]; r.uv[k][1] = v[4];
+                r.n[k] = H3(nm[0] * v[5] + nm[1] * v[6] + nm[2] * v[7], nm[3] * v[5] + nm[4] * v[6] + nm[5] * v[7], nm[6] * v[5] + nm[7] * v[6] + nm[8] * v[7]);
+                const float pc[3] = {r.p[k].x, r.p[k].y, r.p[k].z};
+                BvhBuilder::grow(slo, shi, pc, pc);
+            }
+            h3 c = hcross(hsub(r.p[1], r.p[0]), hsub(r.p[2], r.p[0]));
+            r.ng = hnormalize(c);                       // interaction.py:29, light.py:68
+            r.area = sqrtf(hdot(c, c)) / 2.0f;          // light.py:72
+            r.inst = (int)i; r.prim = t - inst_tri_begin[i];
+        }
+    }
+
+    // acceleration structure: slot order + nodes
+    std::vector<int> order(ntris);
+    for (uint32_t t = 0; t < ntris; t++) order[t] = (int)t;
+    std::vector<float4> nodes;
+    bool use_bvh = (accel == ZDR_ACCEL_BVH) || (accel == ZDR_ACCEL_AUTO && ntris > 64);
+    if (use_bvh) {
+        BvhBuilder bb;
+        bb.prims.resize(ntris);
+        for (uint32_t t = 0; t < ntris; t++) {
+            Prim &p = bb.prims[t]; p.tri = (int)t;
+            for (int k = 0; k < 3; k++) {
+                float a = (&rec[t].p[0].x)[k], b = (&rec[t].p[1].x)[k], c = (&rec[t].p[2].x)[k];
+                p.lo[k] = std::min(a, std::min(b, c)); p.hi[k] = std::max(a, std::max(b, c));
+                p.c[k] = 0.5f * (p.lo[k] + p.hi[k]);
+            }
+        }
+        bb.nodes.reserve(2 * (size_t)ntris / 2 + 16);
+        bb.build(0, (int)ntris, 0);
+        for (uint32_t t = 0; t < ntris; t++) order[t] = bb.prims[t].tri;
+        // conservative padding so that box culling never rejects what the triangle test accepts
+        float diag = sqrtf((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
+        float pad = 4e-6f * diag + 1e-30f;
+        // flatten: inner nodes get consecutive ids in DFS order; the root is id 0 (a lone leaf -> no nodes)
+        std::vector<int> inner_id(bb.nodes.size(), -1);
+        int ninner = 0;
+        for (size_t i = 0; i < bb.nodes.size(); i++) if (bb.nodes[i].count == 0) inner_id[i] = ninner++;
+        nodes.assign(4 * (size_t)ninner, make_float4(0, 0, 0, 0));
+        for (size_t i = 0; i < bb.nodes.size(); i++) {
+            const BNode &n = bb.nodes[i];
+            if (n.count != 0) continue;
+            const BNode &a = bb.nodes[n.left], &b = bb.nodes[n.right];
+            float4 *o = &nodes[4 * (size_t)inner_id[i]];
+            o[0] = make_float4(a.lo[0] - pad, a.lo[1] - pad, a.lo[2] - pad, a.hi[0] + pad);
+            o[1] = make_float4(a.hi[1] + pad, a.hi[2] + pad, b.lo[0] - pad, b.lo[1] - pad);
+            o[2] = make_float4(b.lo[2] - pad, b.hi[0] + pad, b.hi[1] + pad, b.hi[2] + pad);
+            int c0 = a.count ? a.first : inner_id[n.left], c1 = b.count ? b.first : inner_id[n.right];
+            int k0 = a.count, k1 = b.count;
+            float f0, f1, f2, f3; memcpy(&f0, &c0, 4); memcpy(&f1, &c1, 4); memcpy(&f2, &k0, 4); memcpy(&f3, &k1, 4);
+            o[3] = make_float4(f0, f1, f2, f3);
+        }
+        s->bvh_nodes = (uint32_t)ninner; s->bvh_depth = (uint32_t)bb.max_depth;
+    }
+    s->accel_is_bvh = use_bvh ? 1 : 0;
+
+    std::vector<float4> isect(3 * (size_t)ntris), shade(8 * (size_t)ntris);
+    std::vector<int32_t> slot_of_tri(ntris);
+    for (uint32_t slot = 0; slot < ntris; slot++) {
+        const TriRec &r = rec[order[slot]];
+        slot_of_tri[order[slot]] = (int32_t)slot;
+        h3 e1 = hsub(r.p[1], r.p[0]), e2 = hsub(r.p[2], r.p[0]);
+        isect[3 * (size_t)slot + 0] = make_float4(r.p[0].x, r.p[0].y, r.p[0].z, 0.0f);
+        isect[3 * (size_t)slot + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+        isect[3 * (size_t)slot + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        float4 *q = &shade[8 * (size_t)slot];
+        q[0] = make_float4(r.p[0].x, r.p[0].y, r.p[0].z, r.uv[0][0]);
+        q[1] = make_float4(r.p[1].x, r.p[1].y, r.p[1].z, r.uv[0][1]);
+        q[2] = make_float4(r.p[2].x, r.p[2].y, r.p[2].z, r.uv[1][0]);
+        q[3] = make_float4(r.n[0].x, r.n[0].y, r.n[0].z, r.uv[1][1]);
+        q[4] = make_float4(r.n[1].x, r.n[1].y, r.n[1].z, r.uv[2][0]);
+        q[5] = make_float4(r.n[2].x, r.n[2].y, r.n[2].z, r.uv[2][1]);
+        q[6] = make_float4(r.ng.x, r.ng.y, r.ng.z, r.area);
+        float fi, fp; memcpy(&fi, &r.inst, 4); memcpy(&fp, &r.prim, 4);
+        q[7] = make_float4(fi, fp, 0.0f, 0.0f);
+    }
+    std::vector<int32_t> lights; int light_count = 0;
+    light_list(s->emission, ninst, lights, light_count);
+
+    hipError_t e = hipSuccess;
+    auto up = [&](auto **dst, const void *src, size_t bytes) { if (e == hipSuccess) e = upload(dst, src, bytes, &s->device_bytes); };
+    up(&s->d_isect, isect.data(), isect.size() * sizeof(float4));
+    up(&s->d_shade, shade.data(), shade.size() * sizeof(float4));
+    up(&s->d_nodes, nodes.data(), nodes.size() * sizeof(float4));
+    up(&s->d_emission, s->emission.data(), s->emission.size() * sizeof(float));
+    up(&s->d_light_insts, lights.data(), lights.size() * sizeof(int32_t));
+    up(&s->d_inst_tri_begin, s->inst_tri_begin.data(), s->inst_tri_begin.size() * sizeof(int32_t));
+    up(&s->d_slot_of_tri, slot_of_tri.data(), slot_of_tri.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) { std::string m = hipGetErrorString(e); zdr_scene_destroy(s); return fail(ZDR_E_HIP, "scene upload: " + m); }
+    s->ds.isect = s->d_isect; s->ds.shade = s->d_shade; s->ds.nodes = s->d_nodes; s->ds.emission = s->d_emission;
+    s->ds.light_insts = s->d_light_insts; s->ds.inst_tri_begin = s->d_inst_tri_begin; s->ds.slot_of_tri = s->d_slot_of_tri;
+    s->ds.ntris = (int32_t)ntris; s->ds.ninst = (int32_t)ninst; s->ds.light_count = light_count; s->ds.nnodes = (int32_t)s->bvh_nodes;
+    *out = s;
+    return ZDR_OK;
+}
+
+extern "C" int zdr_scene_destroy(zdr_scene *s) {
+    if (!s) return ZDR_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->d_isect); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
+    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_partial); (void)hipFree(s->d_counters);
+    delete s;
+    return ZDR_OK;
+}
+
+extern "C" int zdr_scene_info(const zdr_scene *s, zdr_scene_info_t *info) {
+    if (!s || !info) return fail(ZDR_E_INVALID, "null argument");
+    info->ntris = s->ntris; info->nverts = s->nverts; info->ninst = s->ninst; info->light_count = (uint32_t)s->ds.light_count;
+    info->accel = s->accel_is_bvh ? ZDR_ACCEL_BVH : ZDR_ACCEL_BRUTE;
+    info->bvh_nodes = s->bvh_nodes; info->bvh_max_depth = s->bvh_depth; info->device = s->device; info->device_bytes = s->device_bytes;
+    return ZDR_OK;
+}
+
+extern "C" int zdr_scene_set_emissions(zdr_scene *s, const float *inst_emission, void *stream) {
+    if (!s || !inst_emission) return fail(ZDR_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    s->emission.assign(inst_emission, inst_emission + 3 * (size_t)s->ninst);
+    std::vector<int32_t> lights; int count = 0;
+    light_list(s->emission, s->ninst, lights, count);
+    hipStream_t st = (hipStream_t)stream;
+    // pageable sources: these copies return once the data is staged, so the vectors may go out of scope
+    HIPCHK(hipMemcpyAsync(s->d_emission, s->emission.data(), s->emission.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->d_light_insts, lights.data(), lights.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    s->ds.light_count = count;
+    return ZDR_OK;
+}
+
+extern "C" int zdr_scene_set_pmj02bn_tables(zdr_scene *s, const uint32_t *pmj, uint32_t nsets, uint32_t nsamples,
+                                            const uint16_t *bn, uint32_t ntex, uint32_t bnres) {
+    if (!s || !pmj || !bn || !nsets || !nsamples || !ntex || !bnres) return fail(ZDR_E_INVALID, "bad table arguments");
+    HIPCHK(hipSetDevice(s->device));
+    (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); s->d_pmj = nullptr; s->d_bn = nullptr;
+    HIPCHK(upload(&s->d_pmj, pmj, (size_t)nsets * nsamples * 2 * sizeof(uint32_t), &s->device_bytes));
+    HIPCHK(upload(&s->d_bn, bn, (size_t)ntex * bnres * bnres * sizeof(uint16_t), &s->device_bytes));
+    s->tab.pmj = s->d_pmj; s->tab.bn = s->d_bn; s->tab.nsets = nsets; s->tab.nsamples = nsamples; s->tab.ntex = ntex; s->tab.bnres = bnres;
+    return ZDR_OK;
+}
+
+// ------------------------------------------------------------------------- launch set-up
+static uint32_t smear(uint32_t w) { w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16; return w; }
+static bool is_pow2(uint32_t x) { return x && !(x & (x - 1)); }
+
+static int make_sampler_cfg(const zdr_scene *s, int32_t sampler, uint32_t seed, uint32_t spp, SamplerCfg &C) {
+    if (spp == 0) return fail(ZDR_E_INVALID, "spp must be positive");
+    memset(&C, 0, sizeof C);
+    C.kind = sampler; C.seed = seed; C.spp = spp; C.w = smear(spp - 1);
+    C.res = (uint32_t)(int)sqrtf((float)spp + 0.4f);               // corrmj.py:67
+    if (C.res == 0) C.res = 1;
+    C.resw = smear(C.res - 1);
+    C.spp_pow2 = is_pow2(spp); C.res_pow2 = is_pow2(C.res);
+    C.inv_spp = 1.0f / (float)spp; C.inv_res = 1.0f / (float)C.res;
+    C.res_shift = 0; while ((1u << C.res_shift) < C.res) C.res_shift++;
+    if (sampler == ZDR_SAMPLER_PMJ02BN) {
+        if (!s->d_pmj || !s->d_bn) return fail(ZDR_E_UNSUPPORTED, "PMJ02bn sampler needs tables: call zdr_scene_set_pmj02bn_tables (the reference's own tables are absent)");
+        if (spp > s->tab.nsamples) return fail(ZDR_E_INVALID, "spp exceeds the PMJ02bn table length");
+        C.tab = s->tab;
+    } else if (sampler != ZDR_SAMPLER_CMJ) return fail(ZDR_E_INVALID, "unknown sampler");
+    return ZDR_OK;
+}
+
+static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg &R) {
+    if (p->integrator < 0 || p->integrator > 2) return fail(ZDR_E_INVALID, "unknown integrator");
+    if (p->width <= 0 || p->height <= 0) return fail(ZDR_E_INVALID, "bad resolution");
+    if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 > p->x1 || p->y0 > p->y1) return fail(ZDR_E_INVALID, "bad pixel rectangle");
+    if (p->sample_begin > p->sample_end || p->sample_end > p->spp) return fail(ZDR_E_INVALID, "bad sample range");
+    if (p->tex_h <= 0 || p->tex_w <= 0) return fail(ZDR_E_INVALID, "bad texture size");
+    if (p->max_depth < 1) return fail(ZDR_E_INVALID, "max_depth must be >= 1");
+    if (backward && p->integrator == ZDR_PATH && p->max_depth > ZDR_MAX_RECORDED_DEPTH) return fail(ZDR_E_UNSUPPORTED, "path backward records at most 16 vertices (prb.py:15)");
+    memset(&R, 0, sizeof R);
+    R.width = p->width; R.height = p->height; R.x0 = p->x0; R.y0 = p->y0; R.x1 = p->x1; R.y1 = p->y1;
+    R.sample_begin = p->sample_begin; R.sample_end = p->sample_end;
+    R.use_tent = p->use_tent; R.max_depth = p->max_depth; R.rr_depth = p->rr_depth; R.tex_h = p->tex_h; R.tex_w = p->tex_w;
+    R.two_over_w = 2.0f / (float)p->width; R.two_over_h = 2.0f / (float)p->height;
+    R.aspect = (float)p->height / (float)p->width;
+    R.inv_spp = 1.0f / (float)p->spp;
+    R.alpha = (float)(p->sample_end - p->sample_begin) / (float)p->spp;
+    h3 origin = H3(p->camera.origin[0], p->camera.origin[1], p->camera.origin[2]);
+    h3 target = H3(p->camera.target[0], p->camera.target[1], p->camera.target[2]);
+    h3 up = H3(p->camera.up[0], p->camera.up[1], p->camera.up[2]);
+    h3 fwd = hnormalize(hsub(target, origin));                    // camera.py:12-14
+    h3 right = hnormalize(hcross(fwd, up));
+    h3 upp = hcross(right, fwd);
+    R.cam_o[0] = origin.x; R.cam_o[1] = origin.y; R.cam_o[2] = origin.z;
+    R.cam_fwd[0] = fwd.x; R.cam_fwd[1] = fwd.y; R.cam_fwd[2] = fwd.z;
+    R.cam_right[0] = right.x; R.cam_right[1] = right.y; R.cam_right[2] = right.z;
+    R.cam_upp[0] = upp.x; R.cam_upp[1] = upp.y; R.cam_upp[2] = upp.z;
+    R.cam_tan = tanf(0.5f * p->camera.fov);                       // camera.py:15
+    // work decomposition: 8x8 pixel tiles x sample chunks, enough single-wave workgroups to keep
+    // 256 CUs x 4 SIMDs busy with several waves each and to let the dispatcher balance uneven tiles
+    R.tiles_x = (p->x1 - p->x0 + 7) / 8; R.tiles_y = (p->y1 - p->y0 + 7) / 8;
+    uint32_t ns = p->sample_end - p->sample_begin;
+    long tiles = (long)R.tiles_x * R.tiles_y;
+    long target_waves = 16384;
+    if (const char *e = getenv("ZDR_TARGET_WAVES")) target_waves = std::max(1L, atol(e));
+    uint32_t min_chunk = 16;
+    if (const char *e = getenv("ZDR_MIN_CHUNK")) min_chunk = (uint32_t)std::max(1L, atol(e));
+    long want = tiles > 0 ? (target_waves + tiles - 1) / tiles : 1;
+    long maxc = std::max<long>(1, ns / min_chunk);
+    long nchunks = std::max<long>(1, std::min(want, maxc));
+    R.chunk = ns ? (uint32_t)((ns + nchunks - 1) / nchunks) : 1;
+    R.nchunks = ns ? (int32_t)((ns + R.chunk - 1) / R.chunk) : 0;
+    return ZDR_OK;
+}
+
+static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
+    if (R.nchunks <= 1) return ZDR_OK;
+    size_t need = (size_t)R.nchunks * R.width * R.height * sizeof(float4);
+    if (need > s->partial_bytes) {
+        (void)hipFree(s->d_partial); s->d_partial = nullptr; s->partial_bytes = 0;
+        HIPCHK(hipMalloc((void **)&s->d_partial, need));
+        s->partial_bytes = need;
+    }
+    return ZDR_OK;
+}
+
+static int render_common(zdr_scene *s, const zdr_render_params *p, const float *material, float *image, const float *d_image,
+                         float *d_material, int backward, int stats, void *stream) {
+    if (!s || !p || !material) return fail(ZDR_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    RenderCfg R; SamplerCfg C;
+    int rc = make_render_cfg(p, backward != 0, R); if (rc) return rc;
+    rc = make_sampler_cfg(s, p->sampler, p->seed, p->spp, C); if (rc) return rc;
+    if (stats || backward) { /* no partial images: counters / atomics only */ }
+    else { rc = ensure_partial(s, R); if (rc) return rc; }
+    KernelIO io; memset(&io, 0, sizeof io);
+    io.material = (const float4 *)material; io.image = (float4 *)image; io.partial = s->d_partial;
+    io.d_image = (const float4 *)d_image; io.d_material = d_material; io.counters = s->d_counters;
+    if (zdr_launch_render(s->ds, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
+        return fail(ZDR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(hipGetLastError()));
+    return ZDR_OK;
+}
+
+extern "C" int zdr_render_forward(zdr_scene *s, const zdr_render_params *p, const float *material, float *image, void *stream) {
+    if (!image) return fail(ZDR_E_INVALID, "null image");
+    return render_common(s, p, material, image, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int zdr_render_backward(zdr_scene *s, const zdr_render_params *p, const float *d_image, const float *material,
+                                   float *d_material, void *stream) {
+    if (!d_image || !d_material) return fail(ZDR_E_INVALID, "null gradient buffer");
+    return render_common(s, p, material, nullptr, d_image, d_material, 1, 0, stream);
+}
+
+extern "C" int zdr_render_stats(zdr_scene *s, const zdr_render_params *p, const float *material, uint64_t counters[8], void *stream) {
+    if (!s || !counters) return fail(ZDR_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), st));
+    int rc = render_common(s, p, material, nullptr, nullptr, nullptr, 0, 1, stream); if (rc) return rc;
+    unsigned long long h[8];
+    HIPCHK(hipMemcpyAsync(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 8; i++) counters[i] = h[i];
+    return ZDR_OK;
+}
+
+extern "C" int zdr_trace_closest(zdr_scene *s, const float *rays, uint32_t n, int32_t *inst_prim, float *bary_t, void *stream) {
+    if (!s || !rays || !inst_prim || !bary_t) return fail(ZDR_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    if (zdr_launch_trace(s->ds, s->accel_is_bvh, 0, rays, n, inst_prim, bary_t, (hipStream_t)stream)) return fail(ZDR_E_HIP, "trace launch failed");
+    return ZDR_OK;
+}
+
+extern "C" int zdr_trace_any(zdr_scene *s, const float *rays, uint32_t n, int32_t *occluded, void *stream) {
+    if (!s || !rays || !occluded) return fail(ZDR_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    if (zdr_launch_trace(s->ds, s->accel_is_bvh, 1, rays, n, occluded, nullptr, (hipStream_t)stream)) return fail(ZDR_E_HIP, "trace launch failed");
+    return ZDR_OK;
+}
+
+extern "C" int zdr_sampler_dump(zdr_scene *s, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries, uint32_t n,
+                                int32_t nvert, int32_t rr_depth, float *out, void *stream) {
+    if (!s || !queries || !out || nvert < 0) return fail(ZDR_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(s->device));
+    SamplerCfg C;
+    int rc = make_sampler_cfg(s, sampler, seed, spp, C); if (rc) return rc;
+    if (zdr_launch_sampler_dump(C, queries, n, nvert, rr_depth, out, (hipStream_t)stream)) return fail(ZDR_E_HIP, "sampler dump launch failed");
+    return ZDR_OK;
+}

@@ -1,0 +1,254 @@
+// zdr_kernels.hip — gfx950 kernels of the zdr hot path and their launchers.
+//
+// Mapping: a 64-lane wavefront = one 8x8 pixel tile x one chunk of the sample
+// range; lane = pixel.  Workgroups are single waves, so no workgroup barrier exists anywhere and
+// the hardware can retire/dispatch waves individually (paths have very uneven lengths).  The
+// block index is remapped so that each XCD (blocks b, b+8, ... share one) receives a contiguous
+// run of tiles: primary-hit texel footprints of neighbouring tiles then share that XCD's L2.
+#include "integrators.h"
+#include "zdr.h"
+
+#define WAVE 64
+
+struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk; };
+
+ZD WorkItem decode_block(const RenderCfg &R) {
+    const int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
+    const int per_xcd = (nblocks + 7) >> 3;
+    const int b = blockIdx.x;
+    const int logical = (b & 7) * per_xcd + (b >> 3);       // XCD-contiguous tile runs
+    WorkItem w;
+    w.valid = logical < nblocks;
+    const int tile = logical / R.nchunks;
+    w.chunk = logical - tile * R.nchunks;
+    const int ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+    const int lane = threadIdx.x;
+    w.x = R.x0 + tx * 8 + (lane & 7);
+    w.y = R.y0 + ty * 8 + (lane >> 3);
+    w.valid = w.valid && (w.x < R.x1) && (w.y < R.y1);
+    w.pix = w.x + w.y * R.width;
+    w.s_begin = R.sample_begin + (uint32_t)w.chunk * R.chunk;
+    uint32_t e = w.s_begin + R.chunk;
+    w.s_end = (e < R.sample_end) ? e : R.sample_end;
+    if (!w.valid) w.s_end = w.s_begin;
+    return w;
+}
+
+ZD void store_pixel(const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, const WorkItem &w, f3 sum) {
+    if (!w.valid) return;
+    if (R.nchunks == 1) {   // integrator.py:29: (s / spp, 1)
+        float fs = (float)C.spp;
+        io.image[w.pix] = make_float4(__fdiv_rn(sum.x, fs), __fdiv_rn(sum.y, fs), __fdiv_rn(sum.z, fs), R.alpha);
+    } else {
+        io.partial[(size_t)w.chunk * ((size_t)R.width * R.height) + w.pix] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    }
+}
+
+ZD f3 load_le_grad(const SamplerCfg &C, const KernelIO &io, const WorkItem &w) {   // integrator.py:38-40
+    f3 g = mk3(0.0f);
+    if (w.valid) {
+        float4 gi = io.d_image[w.pix];
+        float fs = (float)C.spp;
+        g = mk3(__fdiv_rn(gi.x, fs), __fdiv_rn(gi.y, fs), __fdiv_rn(gi.z, fs));
+        if (any_nan(g)) g = mk3(0.0f);
+    }
+    return g;
+}
+
+template <bool STATS>
+ZD void flush_counters(const KernelIO &io, const Counters &cnt) {
+    if (!STATS) return;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        unsigned long long v = cnt.c[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+        if (threadIdx.x == 0 && v) atomicAdd(io.counters + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------- path
+template <int SK, class A, bool BWD, bool STATS>
+__global__ __launch_bounds__(WAVE) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+    __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    const WorkItem w = decode_block(R);
+    const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
+    Counters cnt;
+#pragma unroll
+    for (int i = 0; i < 8; i++) cnt.c[i] = 0;
+    f3 le_grad = mk3(0.0f);
+    if (BWD) le_grad = load_le_grad(C, io, w);
+    PathVertex rec[BWD ? ZDR_MAX_RECORDED_DEPTH : 1];
+    int nrec = 0;
+    f3 term_Li = mk3(0.0f);
+
+    f3 sum = mk3(0.0f);
+    uint32_t it = w.s_begin;
+    bool alive = false;
+    PathState ps;
+    ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
+    ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
+    for (;;) {
+        if (!alive && it < w.s_end) {                       // regenerate: next sample of this pixel
+            ps.smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
+            pixel_ray<SK>(R, C, ps.smp, w.x, w.y, ps.o, ps.d);
+            ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;   // prb.py:20-22
+            nrec = 0; term_Li = mk3(0.0f);
+            alive = true; it++;
+            COUNT(C_SAMPLES);
+        }
+        if (__ballot(alive) == 0ull) break;                 // every lane has exhausted its samples
+        if (alive) {
+            bool done = path_bounce<SK, A, BWD, STATS>(S, R, C, io, lds, ps, rec, nrec, term_Li, cnt);
+            if (done) {
+                alive = false;
+                if (!any_nan(ps.L)) {                       // integrator.py:27-28 / prb.py:100
+                    sum = sum + clamp_radiance(ps.L);
+                    if (BWD) path_sweep(R, io, rec, nrec, term_Li, le_grad);
+                } else COUNT(C_NAN);
+            }
+        }
+    }
+    if (!BWD) store_pixel(R, C, io, w, sum);
+    flush_counters<STATS>(io, cnt);
+}
+
+// ---------------------------------------------------------------------- direct / collocated
+template <int INTEG, int SK, class A, bool BWD, bool STATS>
+__global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+    __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    const WorkItem w = decode_block(R);
+    const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
+    Counters cnt;
+#pragma unroll
+    for (int i = 0; i < 8; i++) cnt.c[i] = 0;
+    f3 le_grad = mk3(0.0f);
+    if (BWD) le_grad = load_le_grad(C, io, w);
+    f3 sum = mk3(0.0f);
+    for (uint32_t it = w.s_begin; it < w.s_end; it++) {     // integrator.py:15
+        Sampler smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
+        f3 o, d;
+        pixel_ray<SK>(R, C, smp, w.x, w.y, o, d);
+        COUNT(C_SAMPLES);
+        f3 rad;
+        if (INTEG == ZDR_COLLOCATED) rad = collocated_sample<A, BWD, STATS>(S, R, io, lds, o, d, le_grad, cnt);
+        else rad = direct_sample<SK, A, BWD, STATS>(S, R, C, io, lds, smp, o, d, le_grad, cnt);
+        if (!any_nan(rad)) sum = sum + clamp_radiance(rad); else COUNT(C_NAN);
+    }
+    if (!BWD) store_pixel(R, C, io, w, sum);
+    flush_counters<STATS>(io, cnt);
+}
+
+// sums the per-chunk partial images in chunk order (deterministic), integrator.py:29
+__global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial, float4 *image) {
+    int x = R.x0 + blockIdx.x * blockDim.x + threadIdx.x, y = R.y0 + blockIdx.y;
+    if (x >= R.x1 || y >= R.y1) return;
+    size_t pix = (size_t)x + (size_t)y * R.width, npix = (size_t)R.width * R.height;
+    f3 s = mk3(0.0f);
+    for (int c = 0; c < R.nchunks; c++) { float4 p = partial[(size_t)c * npix + pix]; s = s + mk3(p.x, p.y, p.z); }
+    float fs = (float)spp;
+    image[pix] = make_float4(__fdiv_rn(s.x, fs), __fdiv_rn(s.y, fs), __fdiv_rn(s.z, fs), R.alpha);
+}
+
+// ----------------------------------------------------------------------------------- launch
+template <int SK, class A>
+static void launch_path(dim3 grid, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
+    if (backward) hipLaunchKernelGGL((k_path<SK, A, true, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
+    else if (stats) hipLaunchKernelGGL((k_path<SK, A, false, true>), grid, dim3(WAVE), 0, st, S, R, C, io);
+    else hipLaunchKernelGGL((k_path<SK, A, false, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
+}
+template <int INTEG, int SK, class A>
+static void launch_simple(dim3 grid, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
+    if (backward) hipLaunchKernelGGL((k_simple<INTEG, SK, A, true, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
+    else if (stats) hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, true>), grid, dim3(WAVE), 0, st, S, R, C, io);
+    else hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
+}
+template <int SK, class A>
+static void launch_integ(int integrator, dim3 grid, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
+    if (integrator == ZDR_PATH) launch_path<SK, A>(grid, st, S, R, C, io, backward, stats);
+    else if (integrator == ZDR_DIRECT) launch_simple<ZDR_DIRECT, SK, A>(grid, st, S, R, C, io, backward, stats);
+    else launch_simple<ZDR_COLLOCATED, SK, A>(grid, st, S, R, C, io, backward, stats);
+}
+
+int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
+                      int integrator, int accel_is_bvh, int backward, int stats, hipStream_t st) {
+    int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
+    if (nblocks <= 0) return 0;
+    dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
+    if (C.kind == ZDR_SAMPLER_CMJ) {
+        if (accel_is_bvh) launch_integ<0, BvhAccel>(integrator, grid, st, S, R, C, io, backward, stats);
+        else launch_integ<0, BruteAccel>(integrator, grid, st, S, R, C, io, backward, stats);
+    } else {
+        if (accel_is_bvh) launch_integ<1, BvhAccel>(integrator, grid, st, S, R, C, io, backward, stats);
+        else launch_integ<1, BruteAccel>(integrator, grid, st, S, R, C, io, backward, stats);
+    }
+    if (!backward && !stats && R.nchunks > 1) {
+        dim3 g((R.x1 - R.x0 + 63) / 64, R.y1 - R.y0);
+        hipLaunchKernelGGL(k_reduce_chunks, g, dim3(64), 0, st, R, C.spp, (const float4 *)io.partial, io.image);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------- ray batch queries
+template <class A, bool ANY>
+__global__ __launch_bounds__(WAVE) void k_trace(DScene S, const float4 *rays, uint32_t n, int32_t *out_i, float *out_f) {
+    __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    bool valid = i < n;
+    float4 a = valid ? rays[2 * (size_t)i] : make_float4(0, 0, 0, 0), b = valid ? rays[2 * (size_t)i + 1] : make_float4(0, 0, 1, 0);
+    if (ANY) {
+        bool occ = A::any(S, lds, xyz(a), xyz(b), a.w, b.w);
+        if (valid) out_i[i] = occ ? 1 : 0;
+    } else {
+        Hit h = A::closest(S, lds, xyz(a), xyz(b), a.w, b.w);
+        if (valid) {
+            int inst = -1, prim = -1;
+            if (h.slot >= 0) { float4 r7 = S.shade[8 * (size_t)h.slot + 7]; inst = __float_as_int(r7.x); prim = __float_as_int(r7.y); }
+            out_i[2 * (size_t)i] = inst; out_i[2 * (size_t)i + 1] = prim;
+            out_f[3 * (size_t)i] = h.u; out_f[3 * (size_t)i + 1] = h.v; out_f[3 * (size_t)i + 2] = (h.slot >= 0) ? h.t : b.w;
+        }
+    }
+}
+
+int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *rays, uint32_t n, int32_t *out_i, float *out_f, hipStream_t st) {
+    if (n == 0) return 0;
+    dim3 grid((n + WAVE - 1) / WAVE);
+    const float4 *r = (const float4 *)rays;
+    if (accel_is_bvh) {
+        if (any) hipLaunchKernelGGL((k_trace<BvhAccel, true>), grid, dim3(WAVE), 0, st, S, r, n, out_i, out_f);
+        else hipLaunchKernelGGL((k_trace<BvhAccel, false>), grid, dim3(WAVE), 0, st, S, r, n, out_i, out_f);
+    } else {
+        if (any) hipLaunchKernelGGL((k_trace<BruteAccel, true>), grid, dim3(WAVE), 0, st, S, r, n, out_i, out_f);
+        else hipLaunchKernelGGL((k_trace<BruteAccel, false>), grid, dim3(WAVE), 0, st, S, r, n, out_i, out_f);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------- sampler dump
+template <int SK>
+__global__ void k_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n, int nvert, int rr_depth, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t px = (uint32_t)q[3 * i], py = (uint32_t)q[3 * i + 1], idx = (uint32_t)q[3 * i + 2];
+    uint32_t perm_seed = (SK == 0) ? xxhash32_4(px, py, C.seed, 0u) : 0u;
+    Sampler s = sampler_make<SK>(C, px, py, perm_seed, idx);
+    const int stride = 2 + 8 * nvert;
+    float *o = out + (size_t)i * stride;
+    int k = 0;
+    f2 u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+    for (int v = 0; v < nvert; v++) {
+        o[k++] = sampler_next<SK>(C, s); o[k++] = sampler_next<SK>(C, s);
+        u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+        o[k++] = sampler_next<SK>(C, s);
+        u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+        if (v >= rr_depth) o[k++] = sampler_next<SK>(C, s);
+    }
+    for (; k < stride; k++) o[k] = 0.0f;
+}
+
+int zdr_launch_sampler_dump(const SamplerCfg &C, const int32_t *queries, uint32_t n, int32_t nvert, int32_t rr_depth, float *out, hipStream_t st) {
+    if (n == 0) return 0;
+    dim3 grid((n + 63) / 64);
+    if (C.kind == ZDR_SAMPLER_CMJ) hipLaunchKernelGGL(k_sampler_dump<0>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
+    else hipLaunchKernelGGL(k_sampler_dump<1>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

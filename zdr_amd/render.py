@@ -1,0 +1,207 @@
+"""Python API of the renderer: ``Scene``, ``Camera``, ``float3`` — the reference's public surface
+(/root/reference/render.py:31-257, __init__.py:1) on top of libzdr_hip.so.
+
+    scene = Scene([(obj_path, transform_or_None, emission), ...], integrator="path")
+    scene.camera = Camera(fov=..., origin=float3(...), target=float3(...), up=float3(...))
+    image = scene.render(material, res=(W, H), spp=256, seed=0)      # (H, W, 4) float32, differentiable
+    image.sum().backward()                                            # material.grad: (Ht, Wt, 4)
+
+Images and materials are PyTorch tensors on the GPU; the renderer borrows their device pointers
+for the duration of a call and enqueues its kernels on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .geometry import SceneArrays, assemble, normalize_emission
+from .mathtypes import Camera, float3, float4x4  # noqa: F401  (re-exported)
+
+MAX_DEPTH = 16      # prb.py:15
+RR_DEPTH = 2        # prb.py:16
+
+
+def _camera_pod(cam: Camera) -> N.CameraPOD:
+    return N.CameraPOD(float(cam.fov), (C.c_float * 3)(*cam.origin), (C.c_float * 3)(*cam.target), (C.c_float * 3)(*cam.up))
+
+
+class Scene:
+    """A 3D scene for differentiable rendering w.r.t. one (H, W, 4) material texture
+    (diffuse rgb + roughness; specular fixed at 0.04).  Only the first model is textured; any
+    other model is a light (emission > 0) or a blocker (render.py:31-71, prb.py:45).
+
+    Attributes:
+        camera (Camera): fov (full horizontal angle, radians), origin, target, up.
+        use_tent_filter (bool): tent reconstruction filter if True (default), box filter if False.
+        sampler (str): "cmj" (correlated multi-jitter, corrmj.py — default here) or "pmj02bn"
+            (needs tables, see ``set_pmj02bn_tables``; the reference's tables are not shipped).
+    """
+
+    def __init__(self, models, integrator="direct", *, device=None, accel="auto", sampler="cmj"):
+        integrators = {"path": N.PATH, "direct": N.DIRECT, "collocated": N.COLLOCATED}
+        self._integrator = integrators[integrator]          # KeyError on unknown names, as render.py:70
+        self.integrator = integrator
+        if not torch.cuda.is_available():
+            raise N.ZdrError("zdr_amd needs an AMD GPU (HIP device); there is no CPU back end")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        self.camera = Camera(fov=40 / 180 * 3.1415926, origin=float3(1.0, 0.5, 0.0), target=float3(0.0, 0.0, 0.0), up=float3(0.0, 1.0, 0.0))
+        self.use_tent_filter = True
+        self.sampler = sampler
+        self.max_depth = MAX_DEPTH
+        self.rr_depth = RR_DEPTH
+        self.env_count = 0
+        self._handle = None
+        self.load_geometry(models, accel=accel)
+
+    # ------------------------------------------------------------------ geometry / lights
+    def load_geometry(self, models, accel="auto"):
+        arrays = models if isinstance(models, SceneArrays) else assemble(models)
+        self._arrays = arrays
+        self.inst_count = arrays.ninst
+        self.emissions = [float3(*e) for e in arrays.inst_emission.tolist()]
+        self.light_count = int((arrays.inst_emission > 0).any(axis=1).sum())
+        h = C.c_void_p()
+        L = N.lib()
+        N.check(L.zdr_scene_create(arrays.verts.ctypes.data, arrays.verts.shape[0], arrays.tris.ctypes.data, arrays.tris.shape[0],
+                                   arrays.inst_tri_begin.ctypes.data, arrays.inst_xform.ctypes.data, arrays.inst_emission.ctypes.data,
+                                   arrays.ninst, self.device.index, N.ACCELS[accel], C.byref(h)))
+        self._handle = h
+        self._finalizer = weakref.finalize(self, L.zdr_scene_destroy, h)
+
+    def info(self) -> dict:
+        i = N.SceneInfo()
+        N.check(N.lib().zdr_scene_info(self._handle, C.byref(i)))
+        d = {k: getattr(i, k) for k, _ in N.SceneInfo._fields_}
+        d["accel"] = {N.ACCEL_BRUTE: "brute", N.ACCEL_BVH: "bvh"}[i.accel]
+        return d
+
+    def update_lights(self, emissions):
+        """Rewrite the emission of each mesh in the scene (light-stage style switching);
+        ``emissions`` has one entry per model: None, a number or a float3 (render.py:130-148)."""
+        assert len(emissions) == self.inst_count
+        self.emissions = emissions
+        e = np.ascontiguousarray(np.stack([normalize_emission(x) for x in emissions]), np.float32)
+        self.light_count = int((e > 0).any(axis=1).sum())
+        N.check(N.lib().zdr_scene_set_emissions(self._handle, e.ctypes.data, self._stream()))
+
+    def add_envmap(self, filename, compensate_mis=True):
+        raise NotImplementedError("environment lighting (envmap.py) is outside the hot path built so far (SURVEY §8f-3)")
+
+    def set_pmj02bn_tables(self, pmj_samples, blue_noise):
+        """pmj_samples: uint32 [nsets][nsamples][2]; blue_noise: uint16 [ntex][res][res] (pmj02bn.py:9-18)."""
+        pmj = np.ascontiguousarray(pmj_samples, np.uint32)
+        bn = np.ascontiguousarray(blue_noise, np.uint16)
+        assert pmj.ndim == 3 and pmj.shape[2] == 2 and bn.ndim == 3 and bn.shape[1] == bn.shape[2]
+        N.check(N.lib().zdr_scene_set_pmj02bn_tables(self._handle, pmj.ctypes.data, pmj.shape[0], pmj.shape[1], bn.ctypes.data, bn.shape[0], bn.shape[1]))
+
+    # ------------------------------------------------------------------------- launching
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _params(self, res, spp, seed, tex_hw, rect=None, samples=None, camera=None) -> N.RenderParams:
+        p = N.RenderParams()
+        p.integrator, p.sampler = self._integrator, N.SAMPLERS[self.sampler]
+        p.width, p.height = int(res[0]), int(res[1])
+        p.spp, p.seed = int(spp), int(seed) & 0xFFFFFFFF            # seeds are uint32 (App. B-15)
+        p.use_tent = int(bool(self.use_tent_filter))
+        p.x0, p.y0, p.x1, p.y1 = rect if rect is not None else (0, 0, p.width, p.height)
+        p.sample_begin, p.sample_end = samples if samples is not None else (0, p.spp)
+        p.max_depth, p.rr_depth = int(self.max_depth), int(self.rr_depth)
+        p.camera = _camera_pod(camera if camera is not None else self.camera)
+        p.tex_h, p.tex_w = int(tex_hw[0]), int(tex_hw[1])
+        return p
+
+    def _check_material(self, material):
+        assert material.ndim == 3 and material.shape[2] == 4           # render.py:160,177
+        if material.device != self.device or material.dtype != torch.float32:
+            raise ValueError(f"material must be a float32 tensor on {self.device}")
+
+    def render_forward(self, material, res, spp, seed, *, rect=None, samples=None, out=None):
+        """render.py:159-173.  Returns the (H, W, 4) image; with ``rect``/``samples`` only that shard
+        is written (other pixels of ``out`` keep their value; a fresh image is zero-filled)."""
+        self._check_material(material)
+        material = material.detach().contiguous()
+        if out is None:
+            full = rect is None
+            image = (torch.empty if full else torch.zeros)((res[1], res[0], 4), dtype=torch.float32, device=self.device)
+        else:
+            image = out
+        p = self._params(res, spp, seed, material.shape[0:2], rect, samples)
+        N.check(N.lib().zdr_render_forward(self._handle, C.byref(p), material.data_ptr(), image.data_ptr(), self._stream()))
+        return image
+
+    def render_backward(self, grad_output, d_material, material, res, spp, seed, *, rect=None, samples=None, camera=None):
+        """render.py:176-199: accumulates into ``d_material``; uses ``seed + 1`` like the reference (:196)."""
+        self._check_material(material)
+        material = material.detach().contiguous()
+        g = grad_output.reshape(res[1], res[0], 4).contiguous()
+        assert d_material.is_contiguous() and d_material.shape == material.shape
+        p = self._params(res, spp, seed + 1, material.shape[0:2], rect, samples, camera)
+        N.check(N.lib().zdr_render_backward(self._handle, C.byref(p), g.data_ptr(), material.data_ptr(), d_material.data_ptr(), self._stream()))
+        return d_material, None, None, None, None
+
+    def render_stats(self, material, res, spp, seed=0, *, rect=None, samples=None) -> dict:
+        """Path statistics of one forward pass (camera samples, rays, shaded vertices ...), SURVEY §8d."""
+        self._check_material(material)
+        material = material.detach().contiguous()
+        p = self._params(res, spp, seed, material.shape[0:2], rect, samples)
+        cnt = (C.c_uint64 * 8)()
+        N.check(N.lib().zdr_render_stats(self._handle, C.byref(p), material.data_ptr(), cnt, self._stream()))
+        return dict(zip(N.COUNTER_NAMES, list(cnt)))
+
+    class RenderOperator(torch.autograd.Function):     # render.py:201-223
+        @staticmethod
+        def forward(ctx, material, self, *args):
+            ctx.save_for_backward(material)
+            ctx.scene = weakref.ref(self)
+            ctx.args = args
+            ctx.camera = self.camera.copy()
+            ctx.emissions = self.emissions
+            return self.render_forward(material.detach(), *args)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            scene = ctx.scene()
+            # scene.camera / lights may have changed between forward and backward: replay the
+            # snapshot (camera restored afterwards, lights left at the snapshot — render.py:216-222)
+            if scene.emissions is not ctx.emissions:
+                scene.update_lights(ctx.emissions)
+            material, = ctx.saved_tensors
+            mat_grad = torch.zeros(material.size(), dtype=material.dtype, device=material.device)
+            res, spp, seed = ctx.args
+            return scene.render_backward(grad_output, mat_grad, material.detach(), res, spp, seed, camera=ctx.camera)
+
+    def render(self, material, *, res, spp, seed=0):
+        """Renders the scene; differentiable w.r.t. ``material`` ((Ht, Wt, 4) float32 on the GPU).
+        res = (width, height); returns (height, width, 4) (render.py:225-241)."""
+        return Scene.RenderOperator.apply(material, self, res, spp, seed)
+
+    def render_duvdxy(self, material, *, res, spp, seed=0):
+        raise NotImplementedError("render_duvdxy (uvgrad.py) is outside the hot path built so far (SURVEY §8f-4)")
+
+    # ------------------------------------------------------------------- test / debug hooks
+    def trace_closest(self, rays):
+        """rays: (n, 8) float32 cuda {o, tmin, d, tmax} -> (inst_prim (n,2) int32, bary_t (n,3) float32)."""
+        rays = rays.contiguous()
+        n = rays.shape[0]
+        ip = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+        bt = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        N.check(N.lib().zdr_trace_closest(self._handle, rays.data_ptr(), n, ip.data_ptr(), bt.data_ptr(), self._stream()))
+        return ip, bt
+
+    def trace_any(self, rays):
+        rays = rays.contiguous()
+        occ = torch.empty((rays.shape[0],), dtype=torch.int32, device=self.device)
+        N.check(N.lib().zdr_trace_any(self._handle, rays.data_ptr(), rays.shape[0], occ.data_ptr(), self._stream()))
+        return occ
+
+    def sampler_dump(self, queries, spp, seed=0, nvert=3, rr_depth=RR_DEPTH):
+        """queries: (n, 3) int32 cuda {px, py, sample_index} -> (n, 2 + 8*nvert) float32 sampler draws."""
+        q = queries.to(torch.int32).contiguous()
+        out = torch.empty((q.shape[0], 2 + 8 * nvert), dtype=torch.float32, device=self.device)
+        N.check(N.lib().zdr_sampler_dump(self._handle, N.SAMPLERS[self.sampler], int(seed) & 0xFFFFFFFF, int(spp), q.data_ptr(), q.shape[0], nvert, rr_depth, out.data_ptr(), self._stream()))
+        return out

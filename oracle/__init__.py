@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
 
 COLLOCATED, DIRECT, PATH = 0, 1, 2
 SAMPLER_CMJ, SAMPLER_PMJ02BN = 0, 1
@@ -37,19 +37,24 @@ class Params(C.Structure):
     ]
 
 
-def build(force: bool = False) -> str:
-    so = os.path.join(_HERE, "libzdr_oracle.so")
+VARIANTS = {"ieee": "libzdr_oracle.so", "fma": "libzdr_oracle_fma.so"}
+
+
+def build(force: bool = False, variant: str = "ieee") -> str:
+    """'ieee' is THE oracle (no contraction).  'fma' is the same source compiled with FMA contraction:
+    it differs from 'ieee' only by last-ulp roundings and is used to MEASURE the fp32 noise floor of
+    the reference's formulas (how far two correct float32 evaluations drift apart), never as a reference."""
+    so = os.path.join(_HERE, VARIANTS[variant])
     src = os.path.join(_HERE, "zdr_oracle.c")
     hdr = os.path.join(_HERE, "zdr_oracle.h")
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.run(["make", "-C", _HERE, "-B", "libzdr_oracle.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "-B", VARIANTS[variant]], check=True, capture_output=True)
     return so
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        L = C.CDLL(build())
+def lib(variant: str = "ieee"):
+    if variant not in _LIBS:
+        L = C.CDLL(build(variant=variant))
         fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
         L.zdro_scene_create.restype = C.c_void_p
         L.zdro_scene_create.argtypes = [fp, C.c_int, ip, C.c_int, ip, fp, fp, C.c_int]
@@ -74,8 +79,8 @@ def lib():
         L.zdro_offset_ray_origin.argtypes = [fp, fp, fp]
         L.zdro_read_bsdf.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float, fp]
         L.zdro_set_pmj02bn_tables.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
-        _LIB = L
-    return _LIB
+        _LIBS[variant] = L
+    return _LIBS[variant]
 
 
 def _f(a):
@@ -113,33 +118,34 @@ def make_params(integrator, width, height, spp, seed, camera, tex_hw, *, sampler
 class OracleScene:
     """CPU twin of zdr_amd.Scene's native handle, built from zdr_amd.geometry.SceneArrays-like arrays."""
 
-    def __init__(self, verts, tris, inst_tri_begin, inst_xform, inst_emission):
+    def __init__(self, verts, tris, inst_tri_begin, inst_xform, inst_emission, variant="ieee"):
+        self._L = lib(variant)
         self._keep = [np.ascontiguousarray(verts, np.float32), np.ascontiguousarray(tris, np.int32),
                       np.ascontiguousarray(inst_tri_begin, np.int32), np.ascontiguousarray(inst_xform, np.float32),
                       np.ascontiguousarray(inst_emission, np.float32)]
         v, t, b, x, e = self._keep
         self.ninst = e.reshape(-1, 3).shape[0]
-        self.h = lib().zdro_scene_create(_f(v), v.reshape(-1, 8).shape[0], _i(t), t.reshape(-1, 3).shape[0], _i(b), _f(x), _f(e), self.ninst)
+        self.h = self._L.zdro_scene_create(_f(v), v.reshape(-1, 8).shape[0], _i(t), t.reshape(-1, 3).shape[0], _i(b), _f(x), _f(e), self.ninst)
 
     @classmethod
-    def from_arrays(cls, A):
-        return cls(A.verts, A.tris, A.inst_tri_begin, A.inst_xform, A.inst_emission)
+    def from_arrays(cls, A, variant="ieee"):
+        return cls(A.verts, A.tris, A.inst_tri_begin, A.inst_xform, A.inst_emission, variant=variant)
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().zdro_scene_destroy(self.h)
+            self._L.zdro_scene_destroy(self.h)
             self.h = None
 
     def set_emissions(self, e):
         e = np.ascontiguousarray(e, np.float32).reshape(self.ninst, 3)
-        lib().zdro_scene_set_emissions(self.h, _f(e))
+        self._L.zdro_scene_set_emissions(self.h, _f(e))
 
     def render_forward(self, params: Params, material: np.ndarray, counters: bool = False):
         material = np.ascontiguousarray(material, np.float32)
         assert material.ndim == 3 and material.shape[2] == 4
         img = np.zeros((params.height, params.width, 4), np.float32)
         cnt = (C.c_uint64 * 8)()
-        rc = lib().zdro_render_forward(self.h, C.byref(params), _f(material), _f(img), cnt)
+        rc = self._L.zdro_render_forward(self.h, C.byref(params), _f(material), _f(img), cnt)
         if rc:
             raise RuntimeError(f"oracle forward failed rc={rc}")
         return (img, dict(zip(COUNTER_NAMES, list(cnt)))) if counters else img
@@ -150,7 +156,7 @@ class OracleScene:
         assert d_image.shape == (params.height, params.width, 4)
         dm = np.zeros_like(material)
         cnt = (C.c_uint64 * 8)()
-        rc = lib().zdro_render_backward(self.h, C.byref(params), _f(d_image), _f(material), _f(dm), cnt)
+        rc = self._L.zdro_render_backward(self.h, C.byref(params), _f(d_image), _f(material), _f(dm), cnt)
         if rc:
             raise RuntimeError(f"oracle backward failed rc={rc}")
         return (dm, dict(zip(COUNTER_NAMES, list(cnt)))) if counters else dm
@@ -160,13 +166,13 @@ class OracleScene:
         n = rays.shape[0]
         ip = np.zeros((n, 2), np.int32)
         bt = np.zeros((n, 3), np.float32)
-        lib().zdro_trace_closest(self.h, _f(rays), n, _i(ip), _f(bt))
+        self._L.zdro_trace_closest(self.h, _f(rays), n, _i(ip), _f(bt))
         return ip, bt
 
     def trace_any(self, rays: np.ndarray):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         occ = np.zeros(rays.shape[0], np.int32)
-        lib().zdro_trace_any(self.h, _f(rays), rays.shape[0], _i(occ))
+        self._L.zdro_trace_any(self.h, _f(rays), rays.shape[0], _i(occ))
         return occ
 
 

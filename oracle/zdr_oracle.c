@@ -237,12 +237,17 @@ uint32_t zdro_xxhash32_4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 
 /* corrmj.py:6-28 / pmj02bn.py:33-57 (Kensler's permute; all-uint32, App. B-6) */
 uint32_t zdro_permutation_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
+    /* The hash is a bijection of [0, w]; started inside [0, l) the cycle walk re-enters [0, l)
+     * after at most w + 1 - l rejected values.  The reference loops `while True` and would spin
+     * forever on a start value >= l whose cycle stays outside [0, l) (corrmj.py:109-112 produces such
+     * values when spp is not a perfect square); the walk is bounded here by that exact maximum. */
+    uint32_t budget = w - l + 2u;
     do {
         i ^= p; i *= 0xe170893du; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8;
         i *= 0x0929eb3fu; i ^= p >> 23; i ^= (i & w) >> 1; i *= 1u | p >> 27;
         i *= 0x6935fa69u; i ^= (i & w) >> 11; i *= 0x74dcb303u; i ^= (i & w) >> 2;
         i *= 0x9e501cc3u; i ^= (i & w) >> 2; i *= 0xc860a3dfu; i &= w; i ^= i >> 5;
-    } while (i >= l);
+    } while (i >= l && --budget);
     return (i + p) % l;
 }
 
@@ -259,10 +264,27 @@ void zdro_set_pmj02bn_tables(const uint32_t *pmj, int nsets, int nsamples,
 typedef struct {
     int kind;
     uint32_t px, py, sample_index, dimension, seed, spp, w; /* pmj02bn.py:78-85 */
-    uint32_t permutation_seed, state, res, resw;             /* corrmj.py:48-57 */
+    uint32_t permutation_seed, state;                         /* corrmj.py:48-57 */
+    uint32_t resx, resy, reswx, reswy;                         /* 2-D strata grid, resx * resy >= spp */
 } sampler_t;
 
 static uint32_t smear(uint32_t w) { w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16; return w; }
+
+/* corrmj.py:67 uses res = int(sqrt(spp + 0.4)) for both axes, which is only meaningful when
+ * spp == res * res: otherwise y = index // res reaches values >= res (out of the permutation's
+ * domain, u.y > 1).  Generalisation used here and in the HIP kernels: a resx x resy grid with
+ * resx * resy >= spp — identical to the reference whenever spp is a perfect square. */
+void zdro_cmj_grid(uint32_t spp, uint32_t *resx, uint32_t *resy) {
+    uint32_t res = (uint32_t)(int)sqrtf((float)spp + 0.4f);
+    if (res < 1) res = 1;
+    if (res * res == spp) { *resx = res; *resy = res; return; }
+    if ((spp & (spp - 1)) == 0) { /* 2^(2k+1): 2^(k+1) x 2^k tiles the samples exactly */
+        uint32_t lg = 0; while ((1u << lg) < spp) lg++;
+        *resx = 1u << ((lg + 1) / 2); *resy = spp / *resx; return;
+    }
+    uint32_t m = res; while (m * m < spp) m++;
+    *resx = m; *resy = (spp + m - 1) / m;
+}
 
 static sampler_t make_sampler(int kind, int px, int py, uint32_t seed, uint32_t spp, uint32_t sample_index) {
     sampler_t t; memset(&t, 0, sizeof t);
@@ -270,8 +292,8 @@ static sampler_t make_sampler(int kind, int px, int py, uint32_t seed, uint32_t 
     t.dimension = 0; t.seed = seed; t.spp = spp;
     t.w = smear(spp - 1); /* corrmj.py:61-66, pmj02bn.py:89-94 */
     if (kind == ZDRO_SAMPLER_CMJ) { /* corrmj.py:60-84 */
-        t.res = (uint32_t)(int)sqrtf((float)spp + 0.4f);
-        t.resw = smear(t.res - 1);
+        zdro_cmj_grid(spp, &t.resx, &t.resy);
+        t.reswx = smear(t.resx - 1); t.reswy = smear(t.resy - 1);
         t.permutation_seed = zdro_xxhash32_4(t.px, t.py, seed, 0);
         t.state = zdro_xxhash32_4(t.px, t.py, seed, sample_index);
     }
@@ -312,13 +334,13 @@ static v2 sampler_next2(sampler_t *s) {
     if (s->kind == ZDRO_SAMPLER_CMJ) { /* corrmj.py:105-117 */
         uint32_t ps = s->permutation_seed + s->dimension;
         uint32_t index = zdro_permutation_element(s->sample_index, s->spp, s->w, (ps * 0x51633e2du) & 0x70ffffffu);
-        uint32_t y = index / s->res, x = index % s->res;
-        uint32_t sx = zdro_permutation_element(x, s->res, s->resw, (ps * 0x68bc21ebu) & 0x70ffffffu);
-        uint32_t sy = zdro_permutation_element(y, s->res, s->resw, (ps * 0x02e5be93u) & 0x70ffffffu);
+        uint32_t y = index / s->resx, x = index % s->resx;
+        uint32_t sx = zdro_permutation_element(x, s->resx, s->reswx, (ps * 0x68bc21ebu) & 0x70ffffffu);
+        uint32_t sy = zdro_permutation_element(y, s->resy, s->reswy, (ps * 0x02e5be93u) & 0x70ffffffu);
         float dx = next_lcg(s), dy = next_lcg(s);
-        float fr = (float)s->res;
-        u.x = ((float)x + ((float)sy + dx) / fr) / fr;
-        u.y = ((float)y + ((float)sx + dy) / fr) / fr;
+        float frx = (float)s->resx, fry = (float)s->resy;
+        u.x = ((float)x + ((float)sy + dx) / fry) / frx;
+        u.y = ((float)y + ((float)sx + dy) / frx) / fry;
         s->dimension += 2;
         u.x = clampf(u.x, 0.0f, ONE_MINUS_EPS); u.y = clampf(u.y, 0.0f, ONE_MINUS_EPS);
     } else { /* pmj02bn.py:115-126 */
@@ -558,11 +580,17 @@ void zdro_read_bsdf(const float *m, int tex_h, int tex_w, float u, float v, floa
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 }
 
+static int g_atomic_scatter = 0;
 static void write_single_bsdf_grad(double *dm, int tex_h, int tex_w, int x, int y, float k, v4 g) { /* interaction.py:63-70 */
     x = clampi(x, 0, tex_w - 1); y = clampi(y, 0, tex_h - 1);
     size_t idx = (size_t)x + (size_t)tex_w * y;
-    dm[idx * 4 + 0] += (double)(k * g.x); dm[idx * 4 + 1] += (double)(k * g.y);
-    dm[idx * 4 + 2] += (double)(k * g.z); dm[idx * 4 + 3] += (double)(k * g.w);
+    const double a[4] = {(double)(k * g.x), (double)(k * g.y), (double)(k * g.z), (double)(k * g.w)};
+    for (int c = 0; c < 4; c++) {
+        if (g_atomic_scatter) {
+#pragma omp atomic update
+            dm[idx * 4 + c] += a[c];
+        } else dm[idx * 4 + c] += a[c];
+    }
 }
 static void write_bsdf_grad(double *dm, int tex_h, int tex_w, v2 uv, v4 g) { /* interaction.py:73-89 */
     float px = uv.x * (float)(tex_w - 1), py = (1.0f - uv.y) * (float)(tex_h - 1);
@@ -925,15 +953,13 @@ int zdro_render_backward(const zdro_scene *s, const zdro_params *P, const float 
 #else
     nth = 1;
 #endif
-    double **bufs = (double **)calloc(nth, sizeof(double *));
+    /* one shared float64 accumulator, updated with atomic adds: the stand-in for the reference's
+     * atomic_fetch_add (interaction.py:67-70).  float64 sums make the arrival order irrelevant at
+     * float32 output precision. */
+    double *dm = (double *)calloc(ntex, sizeof(double));
+    g_atomic_scatter = nth > 1;
 #pragma omp parallel num_threads(nth)
     {
-        int tid = 0;
-#ifdef _OPENMP
-        tid = omp_get_thread_num();
-#endif
-        double *dm = (double *)calloc(ntex, sizeof(double));
-        bufs[tid] = dm;
         counters_t C; memset(&C, 0, sizeof C);
 #pragma omp for schedule(dynamic, 1) collapse(2)
         for (int y = P->y0; y < P->y1; y++)
@@ -953,15 +979,9 @@ int zdro_render_backward(const zdro_scene *s, const zdro_params *P, const float 
 #pragma omp critical
         for (int i = 0; i < 8; i++) total.c[i] += C.c[i];
     }
-    /* deterministic reduction: thread buffers summed in thread order, in float64 */
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < ntex; i++) {
-        double acc = 0.0;
-        for (int t = 0; t < nth; t++) if (bufs[t]) acc += bufs[t][i];
-        d_material[i] = (float)((double)d_material[i] + acc);
-    }
-    for (int t = 0; t < nth; t++) free(bufs[t]);
-    free(bufs);
+    for (size_t i = 0; i < ntex; i++) d_material[i] = (float)((double)d_material[i] + dm[i]);
+    free(dm);
     if (counters) memcpy(counters, total.c, sizeof total.c);
     return 0;
 }

@@ -78,6 +78,7 @@ void zdro_trace_any(const zdro_scene *, const float *rays, int n, int32_t *occlu
 /* Known-answer hooks for the unit tests. */
 uint32_t zdro_xxhash32_4(uint32_t x, uint32_t y, uint32_t z, uint32_t w);
 uint32_t zdro_permutation_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p);
+void zdro_cmj_grid(uint32_t spp, uint32_t *resx, uint32_t *resy);
 /* Draw the sampler sequence a path of `nvert` shaded vertices consumes
  * (SURVEY App. A.8): next2f, then per vertex next,next,next2f,next,next2f,(next if k>=rr_depth).
  * out receives the floats in draw order; returns count. */

@@ -21,6 +21,12 @@ def mat_b():
     return fd_material_np(256, 0)
 
 
+@pytest.fixture(scope="module")
+def cbox_oracle_fma(cbox_arrays):
+    # fp32 noise-floor calibration only (see gpu_util.assert_image_parity); never the reference
+    return oracle.OracleScene.from_arrays(cbox_arrays, variant="fma")
+
+
 @pytest.mark.parametrize("integrator,W,spp", [("collocated", 256, 1), ("direct", 128, 16), ("path", 128, 16), ("path", 64, 64)])
 @pytest.mark.parametrize("accel", ["brute", "bvh"])
 def test_forward_matches_oracle(integrator, W, spp, accel, cbox_oracle, mat_a):
@@ -32,41 +38,51 @@ def test_forward_matches_oracle(integrator, W, spp, accel, cbox_oracle, mat_a):
     assert_image_parity(img[..., :3], ref[..., :3], f"{integrator}/{accel} {W}x{W} spp{spp}")
 
 
-def test_forward_box_filter_and_other_seed(cbox_oracle, mat_b):
-    scene = make_scene("path")
+@pytest.mark.parametrize("integrator", ["direct", "path"])
+def test_forward_glossy_material_box_filter_other_seed(integrator, cbox_oracle, cbox_oracle_fma, mat_b):
+    scene = make_scene(integrator)
     scene.use_tent_filter = False
     m = torch.from_numpy(mat_b).cuda()
     img = scene.render(m, res=(96, 96), spp=16, seed=12345).cpu().numpy()
-    ref = cbox_oracle.render_forward(oracle_params(scene, 96, 96, 16, 12345, mat_b.shape[:2]), mat_b)
-    assert_image_parity(img[..., :3], ref[..., :3], "path box-filter seed 12345")
+    p = oracle_params(scene, 96, 96, 16, 12345, mat_b.shape[:2])
+    ref = cbox_oracle.render_forward(p, mat_b)
+    floor = cbox_oracle_fma.render_forward(p, mat_b)
+    assert_image_parity(img[..., :3], ref[..., :3], f"{integrator} glossy box-filter seed 12345", floor=floor[..., :3])
 
 
 @pytest.mark.parametrize("integrator", ["collocated", "direct", "path"])
-def test_backward_matches_oracle(integrator, cbox_oracle, mat_b):
+@pytest.mark.parametrize("material", ["A", "B"])
+def test_backward_matches_oracle(integrator, material, cbox_oracle, cbox_oracle_fma, mat_a, mat_b):
+    mat = mat_a if material == "A" else mat_b
     scene = make_scene(integrator)
     W, spp, seed = 96, 16, 5
     rng = np.random.default_rng(1)
     cot = rng.uniform(0.5, 1.5, (W, W, 4)).astype(np.float32)
-    m = torch.from_numpy(mat_b).cuda().requires_grad_()
+    m = torch.from_numpy(mat).cuda().requires_grad_()
     img = scene.render(m, res=(W, W), spp=spp, seed=seed)
     (img * torch.from_numpy(cot).cuda()).sum().backward()
     # the reference renders the backward pass with seed + 1 (render.py:196)
-    ref = cbox_oracle.render_backward(oracle_params(scene, W, W, spp, seed + 1, mat_b.shape[:2]), cot, mat_b)
-    assert_grad_parity(m.grad.cpu().numpy(), ref, f"backward {integrator}")
+    p = oracle_params(scene, W, W, spp, seed + 1, mat.shape[:2])
+    ref = cbox_oracle.render_backward(p, cot, mat)
+    floor = cbox_oracle_fma.render_backward(p, cot, mat) if material == "B" else None
+    assert_grad_parity(m.grad.cpu().numpy(), ref, f"backward {integrator} material {material}", floor=floor)
 
 
-def test_backward_bvh_path(cbox_oracle, mat_b):
+def test_backward_bvh_path(cbox_oracle, cbox_oracle_fma, mat_b):
     scene = make_scene("path", accel="bvh")
     W, spp, seed = 64, 16, 9
     m = torch.from_numpy(mat_b).cuda().requires_grad_()
     scene.render(m, res=(W, W), spp=spp, seed=seed).sum().backward()
-    ref = cbox_oracle.render_backward(oracle_params(scene, W, W, spp, seed + 1, mat_b.shape[:2]), np.ones((W, W, 4), np.float32), mat_b)
-    assert_grad_parity(m.grad.cpu().numpy(), ref, "backward path/bvh")
+    p = oracle_params(scene, W, W, spp, seed + 1, mat_b.shape[:2])
+    ones = np.ones((W, W, 4), np.float32)
+    ref = cbox_oracle.render_backward(p, ones, mat_b)
+    assert_grad_parity(m.grad.cpu().numpy(), ref, "backward path/bvh", floor=cbox_oracle_fma.render_backward(p, ones, mat_b))
 
 
 def test_terrain_scene_forward_and_backward():
     A = terrain_arrays(n=40)
     S = oracle.OracleScene.from_arrays(A)
+    Sf = oracle.OracleScene.from_arrays(A, variant="fma")
     scene = make_scene("path", arrays=A)
     scene.camera = TERRAIN_CAMERA
     mat = fd_material_np(128, 3)
@@ -75,10 +91,13 @@ def test_terrain_scene_forward_and_backward():
     img = scene.render(m, res=(W, W), spp=spp, seed=2)
     ref = S.render_forward(oracle_params(scene, W, W, spp, 2, mat.shape[:2]), mat)
     assert ref[..., :3].mean() > 0.01
-    assert_image_parity(img.detach().cpu().numpy()[..., :3], ref[..., :3], "terrain path forward")
+    floor = Sf.render_forward(oracle_params(scene, W, W, spp, 2, mat.shape[:2]), mat)
+    assert_image_parity(img.detach().cpu().numpy()[..., :3], ref[..., :3], "terrain path forward", floor=floor[..., :3])
     img.sum().backward()
-    gref = S.render_backward(oracle_params(scene, W, W, spp, 3, mat.shape[:2]), np.ones((W, W, 4), np.float32), mat)
-    assert_grad_parity(m.grad.cpu().numpy(), gref, "terrain path backward")
+    pb = oracle_params(scene, W, W, spp, 3, mat.shape[:2])
+    ones = np.ones((W, W, 4), np.float32)
+    gref = S.render_backward(pb, ones, mat)
+    assert_grad_parity(m.grad.cpu().numpy(), gref, "terrain path backward", floor=Sf.render_backward(pb, ones, mat))
 
 
 def test_shard_unions(mat_a):

@@ -10,7 +10,7 @@ from gpu_util import make_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("spp", [1, 4, 16, 64, 256, 1024, 50, 100])   # includes non-square / non-power-of-two
+@pytest.mark.parametrize("spp", [1, 4, 16, 64, 256, 1024, 2, 8, 32, 128, 100, 50, 12])   # squares, 2^(2k+1), arbitrary
 def test_cmj_draws_bit_exact(spp):
     scene = make_scene("path")
     rng = np.random.default_rng(spp)

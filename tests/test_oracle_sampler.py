@@ -22,13 +22,15 @@ def xxhash_py(x, y, z, w):  # pmj02bn.py:60-74 with Python big ints masked to 32
     return h ^ (h >> 16)
 
 
-def perm_py(i, l, w, p):  # corrmj.py:6-28
+def perm_py(i, l, w, p):  # corrmj.py:6-28, with the walk bounded as in the oracle (see zdro_permutation_element)
+    budget = w - l + 2
     while True:
         i ^= p; i = (i * 0xe170893d) & M; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8
         i = (i * 0x0929eb3f) & M; i ^= p >> 23; i ^= (i & w) >> 1; i = (i * (1 | p >> 27)) & M
         i = (i * 0x6935fa69) & M; i ^= (i & w) >> 11; i = (i * 0x74dcb303) & M; i ^= (i & w) >> 2
         i = (i * 0x9e501cc3) & M; i ^= (i & w) >> 2; i = (i * 0xc860a3df) & M; i &= w; i ^= i >> 5
-        if i < l:
+        budget -= 1
+        if i < l or budget == 0:
             break
     return ((i + p) & M) % l
 
@@ -43,8 +45,18 @@ class CMJPy:  # corrmj.py:60-117
     def __init__(self, px, py, seed, spp, idx):
         f32 = np.float32
         self.idx, self.dim, self.spp, self.w = idx, 0, spp, smear(spp - 1)
-        self.res = int(np.sqrt(f32(spp) + f32(0.4)))
-        self.resw = smear(self.res - 1)
+        res = max(1, int(np.sqrt(f32(spp) + f32(0.4))))
+        if res * res == spp:                     # the reference's domain (corrmj.py:67)
+            self.resx = self.resy = res
+        elif spp & (spp - 1) == 0:               # generalised grid, see zdro_cmj_grid
+            lg = spp.bit_length() - 1
+            self.resx = 1 << ((lg + 1) // 2); self.resy = spp // self.resx
+        else:
+            m = res
+            while m * m < spp:
+                m += 1
+            self.resx, self.resy = m, (spp + m - 1) // m
+        self.reswx, self.reswy = smear(self.resx - 1), smear(self.resy - 1)
         self.ps = xxhash_py(px & M, py & M, seed & M, 0)
         self.state = xxhash_py(px & M, py & M, seed & M, idx)
 
@@ -62,14 +74,14 @@ class CMJPy:  # corrmj.py:60-117
     def next2(self):
         ps = (self.ps + self.dim) & M
         index = perm_py(self.idx, self.spp, self.w, ((ps * 0x51633e2d) & M) & 0x70ffffff)
-        y, x = index // self.res, index % self.res
-        sx = perm_py(x, self.res, self.resw, ((ps * 0x68bc21eb) & M) & 0x70ffffff)
-        sy = perm_py(y, self.res, self.resw, ((ps * 0x02e5be93) & M) & 0x70ffffff)
+        y, x = index // self.resx, index % self.resx
+        sx = perm_py(x, self.resx, self.reswx, ((ps * 0x68bc21eb) & M) & 0x70ffffff)
+        sy = perm_py(y, self.resy, self.reswy, ((ps * 0x02e5be93) & M) & 0x70ffffff)
         dx, dy = self.lcg(), self.lcg()
-        r = np.float32(self.res)
+        rx, ry = np.float32(self.resx), np.float32(self.resy)
         one = np.float32(float.fromhex("0x1.fffffep-1"))
-        ux = (np.float32(x) + (np.float32(sy) + dx) / r) / r
-        uy = (np.float32(y) + (np.float32(sx) + dy) / r) / r
+        ux = (np.float32(x) + (np.float32(sy) + dx) / ry) / rx
+        uy = (np.float32(y) + (np.float32(sx) + dy) / rx) / ry
         self.dim += 2
         return min(max(ux, np.float32(0)), one), min(max(uy, np.float32(0)), one)
 
@@ -101,7 +113,15 @@ def test_permutation_is_bijection_and_matches_python(l):
         assert out == [perm_py(i, l, w, p) for i in range(l)]
 
 
-@pytest.mark.parametrize("spp", [1, 4, 16, 64, 256])
+def test_permutation_walk_is_bounded_for_out_of_domain_starts():
+    # the reference's `while True` spins forever on these (found by search); the bounded walk returns
+    L = oracle.lib()
+    for (i, l, w, p) in [(7, 7, 7, 0x30a9915b), (11, 10, 15, 0x7e7d7f), (50, 50, 63, 0x60093006), (101, 100, 127, 0x604e2746)]:
+        assert L.zdro_permutation_element(i, l, w, p) < l
+        assert L.zdro_permutation_element(i, l, w, p) == perm_py(i, l, w, p)
+
+
+@pytest.mark.parametrize("spp", [1, 4, 16, 64, 256, 2, 8, 32, 128, 50, 12])
 def test_cmj_sequence_bit_exact_vs_python(spp):
     for (px, py, seed) in [(0, 0, 0), (24, 345, 0), (511, 3, 12345), (7, 9, 853402567)]:
         for idx in sorted(set([0, 1, spp // 2, spp - 1])):
@@ -116,6 +136,29 @@ def test_cmj_sequence_bit_exact_vs_python(spp):
             assert got.shape == exp.shape
             assert (got.view(np.uint32) == exp.view(np.uint32)).all()
             assert (got >= 0).all() and (got < 1).all()
+
+
+@pytest.mark.parametrize("spp", [2, 8, 32, 128, 512])
+def test_cmj_2d_non_square_power_of_two_is_stratified(spp):
+    # generalised 2^(k+1) x 2^k grid: one point per cell, each fine stratum of either axis hit once
+    import ctypes as C
+    rx, ry = C.c_uint32(), C.c_uint32()
+    oracle.lib().zdro_cmj_grid(spp, C.byref(rx), C.byref(ry))
+    rx, ry = rx.value, ry.value
+    assert rx * ry == spp and rx in (ry, 2 * ry)
+    pts = np.array([oracle.sampler_dump(oracle.SAMPLER_CMJ, 3, 4, 7, spp, i, nvert=0)[:2] for i in range(spp)])
+    assert (pts >= 0).all() and (pts < 1).all()
+    occ = np.zeros((rx, ry), int)
+    np.add.at(occ, (np.floor(pts[:, 0] * rx).astype(int), np.floor(pts[:, 1] * ry).astype(int)), 1)
+    assert (occ == 1).all()
+    assert sorted(np.floor(pts[:, 0] * spp).astype(int)) == list(range(spp))
+    assert sorted(np.floor(pts[:, 1] * spp).astype(int)) == list(range(spp))
+
+
+def test_cmj_any_spp_stays_in_unit_square_and_terminates():
+    for spp in (3, 5, 12, 50, 99, 1000):
+        pts = np.array([oracle.sampler_dump(oracle.SAMPLER_CMJ, 9, 1, 2, spp, i, nvert=1) for i in range(spp)])
+        assert (pts >= 0).all() and (pts < 1).all()
 
 
 @pytest.mark.parametrize("spp", [16, 64, 256, 1024])

@@ -29,13 +29,17 @@ ZD uint32_t smear_mask(uint32_t w) { w |= w >> 1; w |= w >> 2; w |= w >> 4; w |=
 
 // Kensler's permute (corrmj.py:6-28). When l is a power of two (l == w + 1) the cycle walk never
 // repeats and the final modulo is a mask — true for every BASELINE spp.
+// The reference's `while True` never ends for a start value >= l whose cycle stays outside [0, l);
+// a valid walk rejects at most w + 1 - l values, so the loop is bounded by exactly that: every wave
+// is guaranteed to leave it.
 ZD uint32_t permutation_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
+    uint32_t budget = w - l + 2u;
     do {
         i ^= p; i *= 0xe170893du; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8;
         i *= 0x0929eb3fu; i ^= p >> 23; i ^= (i & w) >> 1; i *= 1u | p >> 27;
         i *= 0x6935fa69u; i ^= (i & w) >> 11; i *= 0x74dcb303u; i ^= (i & w) >> 2;
         i *= 0x9e501cc3u; i ^= (i & w) >> 2; i *= 0xc860a3dfu; i &= w; i ^= i >> 5;
-    } while (i >= l);
+    } while (i >= l && --budget);
     return (l == w + 1u) ? ((i + p) & w) : ((i + p) % l);
 }
 
@@ -43,9 +47,12 @@ ZD uint32_t permutation_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p) 
 struct SamplerCfg {
     int32_t kind;               // ZDR_SAMPLER_*
     uint32_t seed, spp, w;      // w = smear(spp - 1)
-    uint32_t res, resw;         // CMJ: res = int(sqrt(spp + 0.4)) (corrmj.py:67)
-    float inv_spp, inv_res;     // exact when spp / res are powers of two, else unused
-    int32_t spp_pow2, res_pow2, res_shift;
+    // CMJ 2-D strata grid: res_x = res_y = int(sqrt(spp + 0.4)) when spp is a perfect square
+    // (corrmj.py:67); otherwise a res_x x res_y >= spp grid (the reference's formula leaves the
+    // permutation's domain there, see oracle/zdr_oracle.c zdro_cmj_grid)
+    uint32_t res_x, res_y, resw_x, resw_y;
+    float inv_spp, inv_res_x, inv_res_y;   // exact when the divisors are powers of two, else unused
+    int32_t spp_pow2, res_pow2, res_x_shift;
     SamplerTables tab;
 };
 
@@ -105,19 +112,19 @@ ZD f2 sampler_next2(const SamplerCfg &c, Sampler &s) {
         uint32_t ps = s.permutation_seed + s.dimension;
         uint32_t index = permutation_element(s.sample_index, c.spp, c.w, (ps * 0x51633e2du) & 0x70ffffffu);
         uint32_t y, x;
-        if (c.res_pow2) { y = index >> c.res_shift; x = index & (c.res - 1u); }
-        else { y = index / c.res; x = index % c.res; }
-        uint32_t sx = permutation_element(x, c.res, c.resw, (ps * 0x68bc21ebu) & 0x70ffffffu);
-        uint32_t sy = permutation_element(y, c.res, c.resw, (ps * 0x02e5be93u) & 0x70ffffffu);
+        if (c.res_pow2) { y = index >> c.res_x_shift; x = index & (c.res_x - 1u); }
+        else { y = index / c.res_x; x = index % c.res_x; }
+        uint32_t sx = permutation_element(x, c.res_x, c.resw_x, (ps * 0x68bc21ebu) & 0x70ffffffu);
+        uint32_t sy = permutation_element(y, c.res_y, c.resw_y, (ps * 0x02e5be93u) & 0x70ffffffu);
         float dx = next_lcg(s), dy = next_lcg(s);
         float ax = (float)sy + dx, ay = (float)sx + dy;
         if (c.res_pow2) {
-            u.x = ((float)x + ax * c.inv_res) * c.inv_res;
-            u.y = ((float)y + ay * c.inv_res) * c.inv_res;
+            u.x = ((float)x + ax * c.inv_res_y) * c.inv_res_x;
+            u.y = ((float)y + ay * c.inv_res_x) * c.inv_res_y;
         } else {
-            float fr = (float)c.res;
-            u.x = __fdiv_rn((float)x + __fdiv_rn(ax, fr), fr);
-            u.y = __fdiv_rn((float)y + __fdiv_rn(ay, fr), fr);
+            float frx = (float)c.res_x, fry = (float)c.res_y;
+            u.x = __fdiv_rn((float)x + __fdiv_rn(ax, fry), frx);
+            u.y = __fdiv_rn((float)y + __fdiv_rn(ay, frx), fry);
         }
         s.dimension += 2;
         u.x = clampf(u.x, 0.0f, ZDR_ONE_MINUS_EPS); u.y = clampf(u.y, 0.0f, ZDR_ONE_MINUS_EPS);

@@ -330,12 +330,16 @@ static int make_sampler_cfg(const zdr_scene *s, int32_t sampler, uint32_t seed, 
     if (spp == 0) return fail(ZDR_E_INVALID, "spp must be positive");
     memset(&C, 0, sizeof C);
     C.kind = sampler; C.seed = seed; C.spp = spp; C.w = smear(spp - 1);
-    C.res = (uint32_t)(int)sqrtf((float)spp + 0.4f);               // corrmj.py:67
-    if (C.res == 0) C.res = 1;
-    C.resw = smear(C.res - 1);
-    C.spp_pow2 = is_pow2(spp); C.res_pow2 = is_pow2(C.res);
-    C.inv_spp = 1.0f / (float)spp; C.inv_res = 1.0f / (float)C.res;
-    C.res_shift = 0; while ((1u << C.res_shift) < C.res) C.res_shift++;
+    // CMJ strata grid: res x res for perfect squares (corrmj.py:67), else res_x * res_y >= spp
+    uint32_t res = (uint32_t)(int)sqrtf((float)spp + 0.4f);
+    if (res < 1) res = 1;
+    if (res * res == spp) { C.res_x = C.res_y = res; }
+    else if (is_pow2(spp)) { uint32_t lg = 0; while ((1u << lg) < spp) lg++; C.res_x = 1u << ((lg + 1) / 2); C.res_y = spp / C.res_x; }
+    else { uint32_t m = res; while (m * m < spp) m++; C.res_x = m; C.res_y = (spp + m - 1) / m; }
+    C.resw_x = smear(C.res_x - 1); C.resw_y = smear(C.res_y - 1);
+    C.spp_pow2 = is_pow2(spp); C.res_pow2 = is_pow2(C.res_x) && is_pow2(C.res_y);
+    C.inv_spp = 1.0f / (float)spp; C.inv_res_x = 1.0f / (float)C.res_x; C.inv_res_y = 1.0f / (float)C.res_y;
+    C.res_x_shift = 0; while ((1u << C.res_x_shift) < C.res_x) C.res_x_shift++;
     if (sampler == ZDR_SAMPLER_PMJ02BN) {
         if (!s->d_pmj || !s->d_bn) return fail(ZDR_E_UNSUPPORTED, "PMJ02bn sampler needs tables: call zdr_scene_set_pmj02bn_tables (the reference's own tables are absent)");
         if (spp > s->tab.nsamples) return fail(ZDR_E_INVALID, "spp exceeds the PMJ02bn table length");
@@ -411,6 +415,11 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     KernelIO io; memset(&io, 0, sizeof io);
     io.material = (const float4 *)material; io.image = (float4 *)image; io.partial = s->d_partial;
     io.d_image = (const float4 *)d_image; io.d_material = d_material; io.counters = s->d_counters;
+    // every pointer a kernel variant dereferences must be live before anything is launched
+    if (backward && (!io.d_image || !io.d_material)) return fail(ZDR_E_INVALID, "backward needs d_image and d_material");
+    if (!backward && !stats && !io.image) return fail(ZDR_E_INVALID, "forward needs an image");
+    if (!backward && !stats && R.nchunks > 1 && !io.partial) return fail(ZDR_E_NOMEM, "chunk workspace missing");
+    if (stats && !io.counters) return fail(ZDR_E_NOMEM, "counter buffer missing");
     if (zdr_launch_render(s->ds, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
         return fail(ZDR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(hipGetLastError()));
     return ZDR_OK;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WAVE) void k_path(DScene S, RenderCfg R, SamplerCfg
             }
         }
     }
-    if (!BWD) store_pixel(R, C, io, w, sum);
+    if (!BWD && !STATS) store_pixel(R, C, io, w, sum);     // the stats variant owns no image
     flush_counters<STATS>(io, cnt);
 }
 
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerC
         else rad = direct_sample<SK, A, BWD, STATS>(S, R, C, io, lds, smp, o, d, le_grad, cnt);
         if (!any_nan(rad)) sum = sum + clamp_radiance(rad); else COUNT(C_NAN);
     }
-    if (!BWD) store_pixel(R, C, io, w, sum);
+    if (!BWD && !STATS) store_pixel(R, C, io, w, sum);
     flush_counters<STATS>(io, cnt);
 }
 

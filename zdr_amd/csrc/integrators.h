@@ -38,8 +38,10 @@ ZD float4 brdf_grad(float cz_over_pi, float dfdr, f3 ct) {     // d(f cos)[ct] w
 
 // ---------------------------------------------------------------------------- collocated
 // collocated.py:11-31 / 35-57: L = brdf(wo, wo) / t^2
+// BWD: the vertex gradient is returned through (guv, grad) — grad stays 0 when there is nothing to add —
+// and the caller queues it at a reconverged point (scene.h, ScatterQueue).
 template <class A, bool BWD, bool STATS>
-ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io, int *lds, f3 o, f3 d, f3 le_grad, Counters &cnt) {
+ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io, int *lds, f3 o, f3 d, f3 le_grad, Counters &cnt, f2 &guv, float4 &grad) {
     COUNT(C_CLOSEST);
     Hit h = A::closest(S, lds, o, d, 0.0f, 1e30f);
     if (h.slot < 0) return mk3(0.0f);
@@ -53,8 +55,8 @@ ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io,
     GgxTerms g = ggx_terms(wo, wo, m.w);
     float inv_t = rcp(h.t), li = inv_t * inv_t;
     if (BWD) {
-        float4 gr = brdf_grad(wo.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, m.w), le_grad * li);
-        if (!any_nan4(gr)) write_bsdf_grad(io.d_material, it.uv, gr, R.tex_h, R.tex_w);
+        grad = brdf_grad(wo.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, m.w), le_grad * li);
+        guv = it.uv;
     }
     return ggx_brdf_from(g, wo, mk3(m.x, m.y, m.z)) * li;
 }
@@ -63,7 +65,7 @@ ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io,
 // direct.py:21-85 (forward) / 89-167 (adjoint; gradient written once at the primary uv, App. B-11)
 template <int SK, class A, bool BWD, bool STATS>
 ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                    Sampler &smp, f3 o, f3 d, f3 le_grad, Counters &cnt) {
+                    Sampler &smp, f3 o, f3 d, f3 le_grad, Counters &cnt, f2 &guv, float4 &grad) {
     COUNT(C_CLOSEST);
     Hit h = A::closest(S, lds, o, d, 0.0f, 1e30f);
     if (h.slot < 0) return mk3(0.0f);
@@ -128,9 +130,7 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
             }
         }
     }
-    if (BWD) {
-        if (any_nonzero4(mat_grad) && !any_nan4(mat_grad)) write_bsdf_grad(io.d_material, it.uv, mat_grad, R.tex_h, R.tex_w);
-    }
+    if (BWD) { grad = mat_grad; guv = it.uv; }
     return radiance;
 }
 
@@ -241,15 +241,12 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     return stop;
 }
 
-// Adjoint sweep over the recorded vertices, last to first (prb.py:105-187, corrected weight App. B-3)
-ZD void path_sweep(const RenderCfg &R, const KernelIO &io, const PathVertex *rec, int nrec, f3 Li, f3 le_grad) {
-    for (int k = nrec - 1; k >= 0; k--) {
-        PathVertex v = rec[k];
-        f3 ctL = v.bW * le_grad;
-        f3 ct = (v.bpq * Li) * le_grad;
-        float4 a = brdf_grad(v.cL, v.dfLdr, ctL), b = brdf_grad(v.c, v.dfdr, ct);
-        float4 g = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-        Li = v.fLW + v.T * Li;
-        if (any_nonzero4(g) && !any_nan4(g)) write_bsdf_grad(io.d_material, v.uv, g, R.tex_h, R.tex_w);   // prb.py:178-187
-    }
+// One step of the adjoint sweep (prb.py:105-187, corrected weight App. B-3): consumes vertex v,
+// carries Li one vertex towards the camera and returns that vertex's material gradient.
+ZD float4 sweep_vertex(const PathVertex &v, f3 &Li, f3 le_grad) {
+    f3 ctL = v.bW * le_grad;
+    f3 ct = (v.bpq * Li) * le_grad;
+    float4 a = brdf_grad(v.cL, v.dfLdr, ctL), b = brdf_grad(v.c, v.dfdr, ct);
+    Li = v.fLW + v.T * Li;
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }

@@ -20,6 +20,7 @@ struct RenderCfg {
     float inv_spp;                             // 1 / spp as computed by IEEE division
     float alpha;                               // (sample_end - sample_begin) / spp
     float cam_o[3], cam_fwd[3], cam_right[3], cam_upp[3], cam_tan;   // camera.py:12-15
+    int32_t debug_no_scatter;         // timing-only ablation (env ZDR_DEBUG_NO_SCATTER): gradients are computed, not added
 };
 
 struct KernelIO {
@@ -27,7 +28,8 @@ struct KernelIO {
     float4 *image;                    // (H, W) float4
     float4 *partial;                  // nchunks x (H*W) float4 scratch when nchunks > 1
     const float4 *d_image;            // backward: cotangent
-    float *d_material;                // backward: accumulated with float atomics
+    float *d_material;                // backward: += gathered from the staging cells by k_cells_to_grad
+    float *cells;                     // backward: (tex_h + 1) x (tex_w + 1) staging cells of 16 floats, zeroed per call
     unsigned long long *counters;     // stats variant: 8 counters
 };
 

@@ -73,19 +73,72 @@ ZD float4 read_bsdf(const float4 *__restrict__ mat, f2 uv, int tex_h, int tex_w)
     return r;
 }
 
-// write_bsdf_grad (interaction.py:63-89): 4 texels x 4 float atomics (global_atomic_add_f32)
-ZD void write_bsdf_grad(float *__restrict__ dmat, f2 uv, float4 g, int tex_h, int tex_w) {
-    TexFoot f = tex_footprint(uv, tex_h, tex_w);
-    float k00 = (1.0f - f.ox) * (1.0f - f.oy), k01 = (1.0f - f.ox) * f.oy;
-    float k10 = f.ox * (1.0f - f.oy), k11 = f.ox * f.oy;
-    const int idx[4] = {f.i00, f.i01, f.i10, f.i11};
-    const float k[4] = {k00, k01, k10, k11};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float *p = dmat + 4 * (size_t)idx[j];
-        unsafeAtomicAdd(p + 0, k[j] * g.x); unsafeAtomicAdd(p + 1, k[j] * g.y);
-        unsafeAtomicAdd(p + 2, k[j] * g.z); unsafeAtomicAdd(p + 3, k[j] * g.w);
+// ---------------------------------------------------------------- gradient scatter (backward)
+// The reference adds k_ij * dmat to the four texels of the bilinear footprint with 16 float atomics
+// (interaction.py:63-89) — 16 scattered 4-byte requests to the memory-side atomic unit per shaded
+// vertex, which is what bounds the backward pass (README.md:21 warns about it; measured here:
+// 60 of 95 ms).  Same arithmetic, different bookkeeping:
+//  * Corner staging cells.  The four products k00*g, k01*g, k10*g, k11*g of one vertex are added to
+//    ONE 64-byte cell indexed by the footprint's base texel (ix, iy), cell = 16 floats
+//    [corner m = 2*dx + dy][channel].  k_cells_to_grad then gathers, per texel, the (up to four)
+//    cells whose footprint covers it.  CLAMP addressing folds out-of-range bases onto the border
+//    cells, which is exact because the clamped corners coincide (weights sum to the same texel).
+//  * Per-wavefront LDS queue, transposed flush.  Lanes push (cell, g, ox, oy); on flush 16 lanes
+//    serve one vertex (lane j adds float j of the cell), so a wave instruction carries four whole
+//    64-byte cells instead of 64 unrelated dwords: one atomic request per vertex instead of 16.
+#define ZDR_SCATTER_CAP 128          // queue entries per wavefront (7 dwords each)
+
+struct ScatterQueue {                // pointers into this wave's LDS block
+    int *cell; float *g; float *ox; float *oy;
+    int count;                       // wave-uniform
+};
+
+ZD ScatterQueue scatter_queue_init(float *lds) {
+    ScatterQueue q;
+    q.cell = (int *)lds; q.g = lds + ZDR_SCATTER_CAP; q.ox = lds + 5 * ZDR_SCATTER_CAP; q.oy = lds + 6 * ZDR_SCATTER_CAP;
+    q.count = 0;
+    return q;
+}
+#define ZDR_SCATTER_LDS_FLOATS (7 * ZDR_SCATTER_CAP)
+
+// must be called by the whole wave (reconverged control flow)
+ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int lane = threadIdx.x & 63, sub = lane >> 4, j = lane & 15;
+    for (int base = 0; base < q.count; base += 4) {
+        int e = base + sub;
+        if (e < q.count) {
+            int cell = q.cell[e];
+            float gc = q.g[4 * e + (j & 3)];
+            float ox = q.ox[e], oy = q.oy[e];
+            float wx = (j & 8) ? ox : 1.0f - ox;        // corner m = j >> 2: bit 1 -> x + 1, bit 0 -> y + 1
+            float wy = (j & 4) ? oy : 1.0f - oy;
+            unsafeAtomicAdd(cells + 16 * (size_t)cell + j, (wx * wy) * gc);   // k_m * dmat.c, interaction.py:82-89
+        }
     }
+    __builtin_amdgcn_wave_barrier();
+    q.count = 0;
+}
+
+// must be called by the whole wave; lanes with active == false push nothing
+ZD void scatter_push(ScatterQueue &q, float *__restrict__ cells, bool active, f2 uv, float4 g, int tex_h, int tex_w, int ablate) {
+    if (ablate) { asm volatile("" ::"v"(g.x), "v"(g.y), "v"(g.z), "v"(g.w), "v"(uv.x), "v"(uv.y)); return; }
+    unsigned long long mask = __ballot(active);
+    int n = __popcll(mask);
+    if (n == 0) return;
+    if (q.count + n > ZDR_SCATTER_CAP) scatter_flush(q, cells);
+    if (active) {
+        float px = uv.x * (float)(tex_w - 1), py = (1.0f - uv.y) * (float)(tex_h - 1);   // interaction.py:78-80
+        int ix = (int)px, iy = (int)py;
+        float ox = px - (float)ix, oy = py - (float)iy;
+        int cx = clampi(ix, -1, tex_w - 1) + 1, cy = clampi(iy, -1, tex_h - 1) + 1;
+        int slot = q.count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        q.cell[slot] = cx + (tex_w + 1) * cy;
+        q.g[4 * slot] = g.x; q.g[4 * slot + 1] = g.y; q.g[4 * slot + 2] = g.z; q.g[4 * slot + 3] = g.w;
+        q.ox[slot] = ox; q.oy[slot] = oy;
+    }
+    q.count += n;
 }
 
 // ------------------------------------------------------------------------------------ lights

@@ -130,6 +130,7 @@ struct zdr_scene {
     int32_t *d_light_insts = nullptr, *d_inst_tri_begin = nullptr, *d_slot_of_tri = nullptr;
     uint32_t *d_pmj = nullptr; uint16_t *d_bn = nullptr; SamplerTables tab{};
     float4 *d_partial = nullptr; size_t partial_bytes = 0;
+    float *d_cells = nullptr; size_t cells_bytes = 0;       // backward staging cells, (tex_h+1) x (tex_w+1) x 16 floats
     unsigned long long *d_counters = nullptr;
     uint64_t device_bytes = 0;
     DScene ds{};
@@ -283,7 +284,7 @@ extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_isect); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
-    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_partial); (void)hipFree(s->d_counters);
+    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_partial); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
     delete s;
     return ZDR_OK;
 }
@@ -387,6 +388,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     long want = tiles > 0 ? (target_waves + tiles - 1) / tiles : 1;
     long maxc = std::max<long>(1, ns / min_chunk);
     long nchunks = std::max<long>(1, std::min(want, maxc));
+    if (const char *e = getenv("ZDR_DEBUG_NO_SCATTER")) R.debug_no_scatter = atoi(e);
     R.chunk = ns ? (uint32_t)((ns + nchunks - 1) / nchunks) : 1;
     R.nchunks = ns ? (int32_t)((ns + R.chunk - 1) / R.chunk) : 0;
     return ZDR_OK;
@@ -403,6 +405,17 @@ static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
     return ZDR_OK;
 }
 
+static int ensure_cells(zdr_scene *s, const RenderCfg &R, hipStream_t st) {
+    size_t need = (size_t)(R.tex_h + 1) * (R.tex_w + 1) * 16 * sizeof(float);
+    if (need > s->cells_bytes) {
+        (void)hipFree(s->d_cells); s->d_cells = nullptr; s->cells_bytes = 0;
+        HIPCHK(hipMalloc((void **)&s->d_cells, need));
+        s->cells_bytes = need;
+    }
+    HIPCHK(hipMemsetAsync(s->d_cells, 0, need, st));
+    return ZDR_OK;
+}
+
 static int render_common(zdr_scene *s, const zdr_render_params *p, const float *material, float *image, const float *d_image,
                          float *d_material, int backward, int stats, void *stream) {
     if (!s || !p || !material) return fail(ZDR_E_INVALID, "null argument");
@@ -410,13 +423,13 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     RenderCfg R; SamplerCfg C;
     int rc = make_render_cfg(p, backward != 0, R); if (rc) return rc;
     rc = make_sampler_cfg(s, p->sampler, p->seed, p->spp, C); if (rc) return rc;
-    if (stats || backward) { /* no partial images: counters / atomics only */ }
-    else { rc = ensure_partial(s, R); if (rc) return rc; }
+    if (backward) { rc = ensure_cells(s, R, (hipStream_t)stream); if (rc) return rc; }
+    else if (!stats) { rc = ensure_partial(s, R); if (rc) return rc; }
     KernelIO io; memset(&io, 0, sizeof io);
     io.material = (const float4 *)material; io.image = (float4 *)image; io.partial = s->d_partial;
-    io.d_image = (const float4 *)d_image; io.d_material = d_material; io.counters = s->d_counters;
+    io.d_image = (const float4 *)d_image; io.d_material = d_material; io.cells = s->d_cells; io.counters = s->d_counters;
     // every pointer a kernel variant dereferences must be live before anything is launched
-    if (backward && (!io.d_image || !io.d_material)) return fail(ZDR_E_INVALID, "backward needs d_image and d_material");
+    if (backward && (!io.d_image || !io.d_material || !io.cells)) return fail(ZDR_E_INVALID, "backward needs d_image, d_material and the staging cells");
     if (!backward && !stats && !io.image) return fail(ZDR_E_INVALID, "forward needs an image");
     if (!backward && !stats && R.nchunks > 1 && !io.partial) return fail(ZDR_E_NOMEM, "chunk workspace missing");
     if (stats && !io.counters) return fail(ZDR_E_NOMEM, "counter buffer missing");

@@ -30,8 +30,7 @@ ZD WorkItem decode_block(const RenderCfg &R) {
     w.s_begin = R.sample_begin + (uint32_t)w.chunk * R.chunk;
     uint32_t e = w.s_begin + R.chunk;
     w.s_end = (e < R.sample_end) ? e : R.sample_end;
-    if (!w.valid) w.s_end = w.s_begin;
-    return w;
+    return w;   // the sample range is wave-uniform; lanes outside the shard are masked with w.valid
 }
 
 ZD void store_pixel(const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, const WorkItem &w, f3 sum) {
@@ -67,7 +66,8 @@ ZD void flush_counters(const KernelIO &io, const Counters &cnt) {
 }
 
 // ------------------------------------------------------------------------------------- path
-template <int SK, class A, bool BWD, bool STATS>
+// Forward (and the counting variant): flat regeneration loop, one bounce per trip per live lane.
+template <int SK, class A, bool STATS>
 __global__ __launch_bounds__(WAVE) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
     const WorkItem w = decode_block(R);
@@ -75,12 +75,7 @@ __global__ __launch_bounds__(WAVE) void k_path(DScene S, RenderCfg R, SamplerCfg
     Counters cnt;
 #pragma unroll
     for (int i = 0; i < 8; i++) cnt.c[i] = 0;
-    f3 le_grad = mk3(0.0f);
-    if (BWD) le_grad = load_le_grad(C, io, w);
-    PathVertex rec[BWD ? ZDR_MAX_RECORDED_DEPTH : 1];
-    int nrec = 0;
-    f3 term_Li = mk3(0.0f);
-
+    PathVertex *rec = nullptr; int nrec = 0; f3 term_Li = mk3(0.0f);
     f3 sum = mk3(0.0f);
     uint32_t it = w.s_begin;
     bool alive = false;
@@ -88,34 +83,92 @@ __global__ __launch_bounds__(WAVE) void k_path(DScene S, RenderCfg R, SamplerCfg
     ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
     ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
     for (;;) {
-        if (!alive && it < w.s_end) {                       // regenerate: next sample of this pixel
+        if (!alive && w.valid && it < w.s_end) {            // regenerate: next sample of this pixel
             ps.smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
             pixel_ray<SK>(R, C, ps.smp, w.x, w.y, ps.o, ps.d);
             ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;   // prb.py:20-22
-            nrec = 0; term_Li = mk3(0.0f);
             alive = true; it++;
             COUNT(C_SAMPLES);
         }
         if (__ballot(alive) == 0ull) break;                 // every lane has exhausted its samples
         if (alive) {
-            bool done = path_bounce<SK, A, BWD, STATS>(S, R, C, io, lds, ps, rec, nrec, term_Li, cnt);
+            bool done = path_bounce<SK, A, false, STATS>(S, R, C, io, lds, ps, rec, nrec, term_Li, cnt);
             if (done) {
                 alive = false;
-                if (!any_nan(ps.L)) {                       // integrator.py:27-28 / prb.py:100
-                    sum = sum + clamp_radiance(ps.L);
-                    if (BWD) path_sweep(R, io, rec, nrec, term_Li, le_grad);
-                } else COUNT(C_NAN);
+                if (!any_nan(ps.L)) sum = sum + clamp_radiance(ps.L);   // integrator.py:27-28
+                else COUNT(C_NAN);
             }
         }
     }
-    if (!BWD && !STATS) store_pixel(R, C, io, w, sum);     // the stats variant owns no image
+    if (!STATS) store_pixel(R, C, io, w, sum);              // the stats variant owns no image
     flush_counters<STATS>(io, cnt);
+}
+
+// PRB backward as a software pipeline.  Each trip a lane (1) advances its current path by one
+// bounce, recording the shaded vertex, and (2) sweeps up to two vertices of its PREVIOUS path
+// (last to first, carrying Li), queueing their gradients.  Records ping-pong between two
+// per-lane buffers (scratch); a finished path waits only while the sweeper still holds the other
+// buffer.  All queue traffic happens at reconverged points so the whole wave takes part in a flush.
+template <int SK, class A>
+__global__ __launch_bounds__(WAVE) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+    __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
+    const WorkItem w = decode_block(R);
+    const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
+    Counters cnt;
+    const f3 le_grad = load_le_grad(C, io, w);
+    ScatterQueue q = scatter_queue_init(lds_q);
+    PathVertex rec[2][ZDR_MAX_RECORDED_DEPTH];
+    int cur = 0, nrec = 0;
+    f3 term_Li = mk3(0.0f);
+    int sw_k = -1, sw_buf = 1;                              // sweeper: next vertex to consume, its buffer
+    f3 sw_Li = mk3(0.0f);
+    uint32_t it = w.s_begin;
+    bool alive = false, waiting = false;
+    PathState ps;
+    ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
+    ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
+    for (;;) {
+        if (!alive && !waiting && w.valid && it < w.s_end) {
+            ps.smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
+            pixel_ray<SK>(R, C, ps.smp, w.x, w.y, ps.o, ps.d);
+            ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
+            nrec = 0; term_Li = mk3(0.0f);
+            alive = true; it++;
+        }
+        if (__ballot(alive || waiting || sw_k >= 0) == 0ull) break;
+        if (alive) {
+            bool done = path_bounce<SK, A, true, false>(S, R, C, io, lds, ps, rec[cur], nrec, term_Li, cnt);
+            if (done) { alive = false; waiting = true; }
+        }
+        if (waiting && sw_k < 0) {                          // hand the finished path to the sweeper
+            waiting = false;
+            if (!any_nan(ps.L) && nrec > 0) {               // prb.py:100: NaN paths contribute nothing
+                sw_k = nrec - 1; sw_buf = cur; sw_Li = term_Li; cur ^= 1;
+            }
+        }
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            const bool sw = sw_k >= 0;
+            float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            f2 guv; guv.x = 0.0f; guv.y = 0.0f;
+            if (sw) {
+                PathVertex v = rec[sw_buf][sw_k];
+                g = sweep_vertex(v, sw_Li, le_grad);
+                guv = v.uv;
+                sw_k--;
+            }
+            scatter_push(q, io.cells, sw && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
+        }
+    }
+    scatter_flush(q, io.cells);
 }
 
 // ---------------------------------------------------------------------- direct / collocated
 template <int INTEG, int SK, class A, bool BWD, bool STATS>
 __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    __shared__ float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 1];
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     Counters cnt;
@@ -123,19 +176,50 @@ __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerC
     for (int i = 0; i < 8; i++) cnt.c[i] = 0;
     f3 le_grad = mk3(0.0f);
     if (BWD) le_grad = load_le_grad(C, io, w);
+    ScatterQueue q = scatter_queue_init(lds_q);
     f3 sum = mk3(0.0f);
-    for (uint32_t it = w.s_begin; it < w.s_end; it++) {     // integrator.py:15
-        Sampler smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
-        f3 o, d;
-        pixel_ray<SK>(R, C, smp, w.x, w.y, o, d);
-        COUNT(C_SAMPLES);
-        f3 rad;
-        if (INTEG == ZDR_COLLOCATED) rad = collocated_sample<A, BWD, STATS>(S, R, io, lds, o, d, le_grad, cnt);
-        else rad = direct_sample<SK, A, BWD, STATS>(S, R, C, io, lds, smp, o, d, le_grad, cnt);
-        if (!any_nan(rad)) sum = sum + clamp_radiance(rad); else COUNT(C_NAN);
+    for (uint32_t it = w.s_begin; it < w.s_end; it++) {     // integrator.py:15 (wave-uniform trip count)
+        float4 grad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        f2 guv; guv.x = 0.0f; guv.y = 0.0f;
+        if (w.valid) {
+            Sampler smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
+            f3 o, d;
+            pixel_ray<SK>(R, C, smp, w.x, w.y, o, d);
+            COUNT(C_SAMPLES);
+            f3 rad;
+            if (INTEG == ZDR_COLLOCATED) rad = collocated_sample<A, BWD, STATS>(S, R, io, lds, o, d, le_grad, cnt, guv, grad);
+            else rad = direct_sample<SK, A, BWD, STATS>(S, R, C, io, lds, smp, o, d, le_grad, cnt, guv, grad);
+            if (!any_nan(rad)) sum = sum + clamp_radiance(rad); else COUNT(C_NAN);
+        }
+        if (BWD) scatter_push(q, io.cells, w.valid && any_nonzero4(grad) && !any_nan4(grad), guv, grad, R.tex_h, R.tex_w, R.debug_no_scatter);
     }
+    if (BWD) scatter_flush(q, io.cells);
     if (!BWD && !STATS) store_pixel(R, C, io, w, sum);
     flush_counters<STATS>(io, cnt);
+}
+
+// Folds the staging cells into the gradient texture: texel (x, y) receives corner (dx, dy) of every
+// cell (ix, iy) with clamp(ix + dx) == x and clamp(iy + dy) == y — the adjoint of read_bsdf's CLAMP
+// bilinear lookup (interaction.py:47-60, 73-89).  Deterministic summation order.
+__global__ void k_cells_to_grad(const float4 *__restrict__ cells, float4 *__restrict__ dmat, int tex_h, int tex_w) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= tex_w) return;
+    int ixs[3], dxs[3], nx = 0, iys[3], dys[3], ny = 0;
+    ixs[nx] = x - 1; dxs[nx++] = 1; ixs[nx] = x; dxs[nx++] = 0;
+    if (x == 0) { ixs[nx] = -1; dxs[nx++] = 0; }
+    if (x == tex_w - 1) { ixs[nx] = tex_w - 1; dxs[nx++] = 1; }
+    iys[ny] = y - 1; dys[ny++] = 1; iys[ny] = y; dys[ny++] = 0;
+    if (y == 0) { iys[ny] = -1; dys[ny++] = 0; }
+    if (y == tex_h - 1) { iys[ny] = tex_h - 1; dys[ny++] = 1; }
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int b = 0; b < ny; b++)
+        for (int a = 0; a < nx; a++) {
+            size_t cell = (size_t)(ixs[a] + 1) + (size_t)(tex_w + 1) * (iys[b] + 1);
+            float4 c = cells[4 * cell + 2 * dxs[a] + dys[b]];
+            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+        }
+    float4 d = dmat[(size_t)x + (size_t)tex_w * y];
+    dmat[(size_t)x + (size_t)tex_w * y] = make_float4(d.x + acc.x, d.y + acc.y, d.z + acc.z, d.w + acc.w);
 }
 
 // sums the per-chunk partial images in chunk order (deterministic), integrator.py:29
@@ -152,9 +236,9 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 // ----------------------------------------------------------------------------------- launch
 template <int SK, class A>
 static void launch_path(dim3 grid, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
-    if (backward) hipLaunchKernelGGL((k_path<SK, A, true, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
-    else if (stats) hipLaunchKernelGGL((k_path<SK, A, false, true>), grid, dim3(WAVE), 0, st, S, R, C, io);
-    else hipLaunchKernelGGL((k_path<SK, A, false, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
+    if (backward) hipLaunchKernelGGL((k_path_bwd<SK, A>), grid, dim3(WAVE), 0, st, S, R, C, io);
+    else if (stats) hipLaunchKernelGGL((k_path<SK, A, true>), grid, dim3(WAVE), 0, st, S, R, C, io);
+    else hipLaunchKernelGGL((k_path<SK, A, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
 }
 template <int INTEG, int SK, class A>
 static void launch_simple(dim3 grid, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
@@ -180,6 +264,10 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     } else {
         if (accel_is_bvh) launch_integ<1, BvhAccel>(integrator, grid, st, S, R, C, io, backward, stats);
         else launch_integ<1, BruteAccel>(integrator, grid, st, S, R, C, io, backward, stats);
+    }
+    if (backward) {   // fold the staging cells into d_material (+=)
+        dim3 g((R.tex_w + 63) / 64, R.tex_h);
+        hipLaunchKernelGGL(k_cells_to_grad, g, dim3(64), 0, st, (const float4 *)io.cells, (float4 *)io.d_material, R.tex_h, R.tex_w);
     }
     if (!backward && !stats && R.nchunks > 1) {
         dim3 g((R.x1 - R.x0 + 63) / 64, R.y1 - R.y0);

@@ -44,8 +44,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     common = [f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     objs = []
     jobs = [
-        # kernels: default contraction (FMA) for speed; NO fast-math (NaN policy, integrator.py:27)
-        ("zdr_kernels.hip", ["-O3", "-munsafe-fp-atomics"]),
+        # kernels: default contraction (FMA) for speed; NO fast-math (NaN policy, integrator.py:27).
+        # -fno-slp-vectorize: hipcc otherwise packs scalar f32 math into v_pk_*_f32, which on gfx950
+        # runs at the same FLOP rate as the scalar forms and pays extra moves to build register
+        # pairs: measured 23.9 -> 17.7 ms on the cbox forward pass (profiles/r1_ab_flags.txt).
+        ("zdr_kernels.hip", ["-O3", "-munsafe-fp-atomics", "-fno-slp-vectorize", *os.environ.get("ZDR_KERNEL_FLAGS", "").split()]),
         # host side: IEEE float32 for the per-triangle constants
         ("zdr_api.cpp", ["-O2", "-ffp-contract=off", "-x", "hip"]),
     ]

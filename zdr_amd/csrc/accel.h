@@ -8,6 +8,19 @@
 #pragma once
 #include "scene.h"
 
+#ifndef ZDR_TRI_UNROLL
+#define ZDR_TRI_UNROLL 1
+#endif
+
+
+// The triangle array is read-only for the whole launch.  Reading it through the CONSTANT address
+// space makes every wave-uniform fetch a scalar load (s_load_dwordx4 into SGPRs) even in kernels
+// that also issue atomics or scratch stores — without it the backward kernel fell back to per-lane
+// global loads (6.5e8 VMEM reads per launch, 59 % of wave time in s_waitcnt).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(4))) *const_v4f_ptr;
+ZD const_v4f_ptr as_constant(const float4 *p) { return (const_v4f_ptr)(uintptr_t)p; }
+ZD float4 f4(v4f a) { return make_float4(a.x, a.y, a.z, a.w); }
 
 ZD bool tri_test(float4 a, float4 b, float4 c, f3 o, f3 d, float tmin, float tmax, float &t, float &u, float &v) {
     f3 v0 = xyz(a), e1 = xyz(b), e2 = xyz(c);
@@ -28,18 +41,22 @@ struct BruteAccel {
     static constexpr bool kNeedsLds = false;
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
+        const_v4f_ptr tri = as_constant(S.isect);
+#pragma unroll ZDR_TRI_UNROLL
         for (int s = 0; s < S.ntris; s++) {
             float t, u, v;
-            bool ok = tri_test(S.isect[3 * s], S.isect[3 * s + 1], S.isect[3 * s + 2], o, d, tmin, h.t, t, u, v);
+            bool ok = tri_test(f4(tri[3 * s]), f4(tri[3 * s + 1]), f4(tri[3 * s + 2]), o, d, tmin, h.t, t, u, v);
             h.t = ok ? t : h.t; h.u = ok ? u : h.u; h.v = ok ? v : h.v; h.slot = ok ? s : h.slot;
         }
         return h;
     }
     ZD static bool any(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         bool occ = false;
+        const_v4f_ptr tri = as_constant(S.isect);
+#pragma unroll ZDR_TRI_UNROLL
         for (int s = 0; s < S.ntris; s++) {
             float t, u, v;
-            occ |= tri_test(S.isect[3 * s], S.isect[3 * s + 1], S.isect[3 * s + 2], o, d, tmin, tmax, t, u, v);
+            occ |= tri_test(f4(tri[3 * s]), f4(tri[3 * s + 1]), f4(tri[3 * s + 2]), o, d, tmin, tmax, t, u, v);
         }
         return occ;
     }

@@ -9,6 +9,9 @@
 #include "zdr.h"
 
 #define WAVE 64
+#ifndef ZDR_MIN_WAVES
+#define ZDR_MIN_WAVES 1
+#endif
 
 struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk; };
 
@@ -68,7 +71,7 @@ ZD void flush_counters(const KernelIO &io, const Counters &cnt) {
 // ------------------------------------------------------------------------------------- path
 // Forward (and the counting variant): flat regeneration loop, one bounce per trip per live lane.
 template <int SK, class A, bool STATS>
-__global__ __launch_bounds__(WAVE) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(WAVE) void k_path(DScene S, RenderCfg R, SamplerCfg
 // per-lane buffers (scratch); a finished path waits only while the sweeper still holds the other
 // buffer.  All queue traffic happens at reconverged points so the whole wave takes part in a flush.
 template <int SK, class A>
-__global__ __launch_bounds__(WAVE) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
     const WorkItem w = decode_block(R);

@@ -1,0 +1,97 @@
+"""The N > 1 path on CPU: two gloo ranks run zdr_amd.distributed with the ORACLE as the local
+renderer (the product renderer needs a GPU) and must reproduce the unsharded render."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import CBOX_CAMERA, cbox_models, fd_material_np
+
+W, SPP, SEED = 24, 16, 3
+
+
+def _oracle_renderer(mode):
+    import oracle
+    from zdr_amd import distributed as zd
+    from zdr_amd import geometry
+    S = oracle.OracleScene.from_arrays(geometry.assemble(cbox_models()))
+
+    def fwd(material, res, spp, seed, rect, samples, out):
+        p = oracle.make_params("path", res[0], res[1], spp, seed, CBOX_CAMERA, tuple(material.shape[:2]), rect=rect, samples=samples, nthreads=2)
+        img = torch.from_numpy(S.render_forward(p, material.numpy()))
+        x0, y0, x1, y1 = rect
+        out[y0:y1, x0:x1] = img[y0:y1, x0:x1]
+        return out
+
+    def bwd(grad_output, d_material, material, res, spp, seed, rect, samples):
+        p = oracle.make_params("path", res[0], res[1], spp, seed + 1, CBOX_CAMERA, tuple(material.shape[:2]), rect=rect, samples=samples, nthreads=2)
+        d_material += torch.from_numpy(S.render_backward(p, grad_output.numpy(), material.numpy()))
+
+    return zd.ShardedRenderer(fwd, bwd, mode)
+
+
+def _worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from zdr_amd import distributed as zd
+    assert zd.init_from_env("gloo") == (rank, world, rank)
+    r = _oracle_renderer(mode)
+    m = torch.from_numpy(fd_material_np(32, 2)).requires_grad_()
+    img = r.render(m, res=(W, W), spp=SPP, seed=SEED)
+    (img * 0.5).sum().backward()
+    if rank == 0:
+        q.put((img.detach().numpy(), m.grad.numpy()))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("mode", ["rows", "samples", "seeds"])
+def test_two_ranks_reproduce_the_single_process_render(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs: p.start()
+    img, grad = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    import oracle
+    from zdr_amd import distributed as zd, geometry
+    S = oracle.OracleScene.from_arrays(geometry.assemble(cbox_models()))
+    mat = fd_material_np(32, 2)
+    cot = np.full((W, W, 4), 0.5, np.float32)
+
+    def single(seed):
+        pf = oracle.make_params("path", W, W, SPP, seed, CBOX_CAMERA, mat.shape[:2])
+        pb = oracle.make_params("path", W, W, SPP, seed + 1, CBOX_CAMERA, mat.shape[:2])
+        return S.render_forward(pf, mat), S.render_backward(pb, cot, mat)
+
+    if mode == "seeds":
+        a, b = single(SEED), single((SEED + zd.SEED_STRIDE) & 0xFFFFFFFF)
+        ref_img, ref_grad = 0.5 * (a[0] + b[0]), 0.5 * (a[1] + b[1])
+    else:
+        ref_img, ref_grad = single(SEED)
+    if mode == "rows":
+        assert np.array_equal(img, ref_img)                     # pixel tiles: bit-identical union
+    else:
+        np.testing.assert_allclose(img, ref_img, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(grad, ref_grad, rtol=1e-4, atol=1e-7)
+
+
+def test_shard_plans_cover_the_work_exactly():
+    from zdr_amd import distributed as zd
+    for world in (1, 2, 3, 8):
+        rows = np.zeros(512, int); samples = np.zeros(256, int)
+        for r in range(world):
+            for (x0, y0, x1, y1) in zd.plan("rows", r, world, (512, 512), 256, 0).rects:
+                assert (x0, x1) == (0, 512); rows[y0:y1] += 1
+            b, e = zd.plan("samples", r, world, (512, 512), 256, 0).samples
+            samples[b:e] += 1
+        assert (rows == 1).all() and (samples == 1).all()
+    assert len({zd.plan("seeds", r, 8, (8, 8), 4, 5).seed for r in range(8)}) == 8

@@ -1,0 +1,72 @@
+"""Golden fixtures (tests/golden/cbox_golden.npz, made by tests/golden/make_golden.py from the
+oracle): the oracle must keep reproducing them exactly (CPU), the HIP path must match them within
+the stated fp32 tolerance (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import CBOX_CAMERA, GOLDEN
+
+sys_path_golden = os.path.join(GOLDEN, "cbox_golden.npz")
+
+
+def load():
+    return np.load(sys_path_golden)
+
+
+def cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m.CASES
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c[0])
+def test_oracle_reproduces_golden(case, cbox_oracle):
+    name, integ, W, spp, seed, tent = case
+    G = load(); mat = G["material"]
+    p = oracle.make_params(integ, W, W, spp, seed, CBOX_CAMERA, mat.shape[:2], use_tent=tent, nthreads=1)
+    assert np.array_equal(cbox_oracle.render_forward(p, mat), G[name + "/image"])
+    pb = oracle.make_params(integ, W, W, spp, seed + 1, CBOX_CAMERA, mat.shape[:2], use_tent=tent, nthreads=1)
+    g = cbox_oracle.render_backward(pb, np.ones((W, W, 4), np.float32), mat)
+    np.testing.assert_allclose(g, G[name + "/grad"], rtol=1e-6, atol=1e-9)
+
+
+def test_oracle_sampler_reproduces_golden():
+    G = load()
+    got = np.stack([oracle.sampler_dump(oracle.SAMPLER_CMJ, 24, 345, 0, 16, i, nvert=3) for i in range(16)])
+    assert np.array_equal(got.view(np.uint32), G["sampler_cmj_px24_py345_seed0_spp16"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c[0])
+def test_hip_matches_golden(case, cbox_arrays):
+    import torch
+    from gpu_util import assert_grad_parity, assert_image_parity, make_scene
+    name, integ, W, spp, seed, tent = case
+    G = load(); mat = G["material"]
+    scene = make_scene(integ)
+    scene.use_tent_filter = tent
+    m = torch.from_numpy(mat).cuda().requires_grad_()
+    img = scene.render(m, res=(W, W), spp=spp, seed=seed)
+    img.sum().backward()
+    # glossy material: calibrate with the fma build of the oracle (see gpu_util.assert_image_parity)
+    Sf = oracle.OracleScene.from_arrays(cbox_arrays, variant="fma")
+    p = oracle.make_params(integ, W, W, spp, seed, CBOX_CAMERA, mat.shape[:2], use_tent=tent)
+    pb = oracle.make_params(integ, W, W, spp, seed + 1, CBOX_CAMERA, mat.shape[:2], use_tent=tent)
+    assert_image_parity(img.detach().cpu().numpy()[..., :3], G[name + "/image"][..., :3], "golden " + name, floor=Sf.render_forward(p, mat)[..., :3])
+    assert_grad_parity(m.grad.cpu().numpy(), G[name + "/grad"], "golden grad " + name, floor=Sf.render_backward(pb, np.ones((W, W, 4), np.float32), mat))
+
+
+@pytest.mark.gpu
+def test_hip_sampler_matches_golden():
+    import torch
+    from gpu_util import make_scene
+    G = load()
+    scene = make_scene("path")
+    q = torch.tensor([[24, 345, i] for i in range(16)], dtype=torch.int32, device="cuda")
+    got = scene.sampler_dump(q, 16, seed=0, nvert=3).cpu().numpy()
+    exp = G["sampler_cmj_px24_py345_seed0_spp16"]
+    assert np.array_equal(got[:, :exp.shape[1]].view(np.uint32), exp.view(np.uint32))

@@ -1,0 +1,89 @@
+"""CPU-side checks of the product: the C-ABI library builds, loads and exports every symbol that
+include/zdr.h declares (no compute calls without a GPU); OBJ ingest; scene assembly; value types."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, ROOT, cbox_models
+from zdr_amd import Camera, _native, float3, float4x4, geometry
+from zdr_amd.load_obj import concat_triangles, read_obj
+
+
+def test_library_exports_every_symbol_of_the_header():
+    hdr = open(os.path.join(ROOT, "include", "zdr.h")).read()
+    declared = set(re.findall(r"\b(zdr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    L = _native.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.zdr_version().decode().startswith("zdr-mi355x")
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_native.CameraPOD) == 40
+    assert C.sizeof(_native.RenderParams) == 4 * 15 + 40 + 8
+    assert _native.RenderParams.camera.offset == 60 and _native.RenderParams.tex_h.offset == 100
+    assert C.sizeof(_native.SceneInfo) == 40
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import zdr_amd
+    with pytest.raises(_native.ZdrError, match="no CPU back end"):
+        zdr_amd.Scene(cbox_models(), integrator="path")
+
+
+def test_scene_create_rejects_bad_input_without_touching_a_gpu():
+    L = _native.lib()
+    h = C.c_void_p()
+    v = np.zeros((3, 8), np.float32); t = np.array([[0, 1, 5]], np.int32); b = np.array([0, 1], np.int32); e = np.zeros((1, 3), np.float32)
+    rc = L.zdr_scene_create(v.ctypes.data, 3, t.ctypes.data, 1, b.ctypes.data, None, e.ctypes.data, 1, 0, 0, C.byref(h))
+    assert rc == -1 and b"out of range" in L.zdr_last_error()
+    rc = L.zdr_scene_create(v.ctypes.data, 3, t.ctypes.data, 0, b.ctypes.data, None, e.ctypes.data, 1, 0, 0, C.byref(h))
+    assert rc == -1 and b"empty" in L.zdr_last_error()
+
+
+def test_read_obj_matches_survey_facts():
+    verts, faces = read_obj(os.path.join(ASSETS, "cboxuv.obj"))
+    assert len(verts) == 60 and len(concat_triangles(faces)) // 3 == 30
+    lv, lf = read_obj(os.path.join(ASSETS, "cbox-light.obj"))
+    assert len(lv) == 4 and len(lf) == 2 and all(np.isnan(x) is np.False_ or True for x in lv[0][2])
+    assert lv[0][1] == (0.0, 0.0)                                       # missing vt -> (0, 0)
+
+
+def test_normal_less_obj_gets_flat_recomputed_normals():
+    A = geometry.assemble([(os.path.join(ASSETS, "quad.obj"), None, 5)])   # 'f 4 3 2 1': no vt, no vn
+    assert A.verts.shape == (4, 8) and A.tris.shape == (2, 3)
+    np.testing.assert_allclose(A.verts[:, 5:8], np.tile([0, -1, 0], (4, 1)), atol=1e-6)
+    assert (A.inst_emission == 5).all()
+
+
+def test_fan_triangulation_and_dedup(tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1 4/1/1\nf 1/1/1 3/1/1 4/1/1\n")
+    verts, faces = read_obj(str(p))
+    assert len(verts) == 4 and faces == [[0, 1, 2, 3], [0, 2, 3]]
+    assert concat_triangles(faces) == [0, 1, 2, 0, 2, 3, 0, 2, 3]
+
+
+def test_assemble_cbox():
+    A = geometry.assemble(cbox_models())
+    assert A.verts.shape == (64, 8) and A.tris.shape == (32, 3) and list(A.inst_tri_begin) == [0, 30, 32]
+    np.testing.assert_allclose(A.verts[:, :3].min(0), [-3.014011, -0.162685, -5.839967], atol=1e-6)
+    assert (A.inst_emission[1] == 20).all() and (A.inst_emission[0] == 0).all()
+    with pytest.raises(RuntimeError, match="maximum number"):
+        geometry.assemble(cbox_models() * 5001)
+
+
+def test_value_types():
+    assert tuple(float3(2)) == (2.0, 2.0, 2.0) and tuple(float3(1, 2, 3)) == (1.0, 2.0, 3.0)
+    m = np.arange(16, dtype=np.float64).reshape(4, 4)
+    np.testing.assert_array_equal(float4x4(*m.transpose().flatten()).rows(), m)   # column-major ctor, test_lightstage.py:44
+    np.testing.assert_array_equal(float4x4(1.0).rows(), np.eye(4))
+    c = Camera(fov=0.5, origin=float3(1, 2, 3), target=float3(0), up=float3(0, 1, 0))
+    assert c.copy().origin == c.origin and c.copy() is not c

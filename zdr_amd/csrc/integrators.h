@@ -154,10 +154,12 @@ struct PathState {
 };
 
 // Advance one live path by one bounce (prb.py:23-87 is the body of `for depth in range(max_depth)`).
-// Returns true when the path has terminated.  BWD: appends to rec[nrec] and sets term_Li.
+// Returns true when the path has terminated.  BWD: fills pv and sets has_vertex when a vertex was
+// shaded, and sets term_Li when the path ended on an emitter.
 template <int SK, class A, bool BWD, bool STATS>
 ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                    PathState &ps, PathVertex *rec, int &nrec, f3 &term_Li, Counters &cnt) {
+                    PathState &ps, PathVertex &pv, bool &has_vertex, f3 &term_Li, Counters &cnt) {
+    has_vertex = false;
     COUNT(C_CLOSEST);
     Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
     if (h.slot < 0) return true;                                                  // prb.py:26-32, env_count == 0
@@ -177,8 +179,8 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
     f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
     COUNT(C_SHADED);
-    PathVertex pv;
     if (BWD) {
+        has_vertex = true;
         pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
         pv.T = mk3(0.0f); pv.fLW = mk3(0.0f);
     }
@@ -235,18 +237,36 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
             pv.T = f * inv_pq;
         }
     }
-    if (BWD) { rec[nrec] = pv; nrec++; }
     ps.depth++;
     if (ps.depth >= R.max_depth) stop = true;
     return stop;
 }
 
-// One step of the adjoint sweep (prb.py:105-187, corrected weight App. B-3): consumes vertex v,
+// The vertex as the sweep stores it: 16 floats = four float4 (one LDS / scratch line per lane).
+// The NEE part of the gradient does not depend on the rest of the path, so it is contracted with the
+// pixel cotangent g at once; the BSDF part keeps only what multiplies Li:
+//   a = d f^L[bW g]                      (4)   NEE gradient of this vertex
+//   b = {Q = bpq g c, r = dfdr / c}      (4)   BSDF gradient = (Q Li, r sum(Q Li))
+//   c = {T, uv.x}, d = {A = fLW, uv.y}   (8)   Li_k = A + T Li_{k+1}
+struct PackedVertex { float4 a, b, c, d; };
+
+ZD PackedVertex pack_vertex(const PathVertex &v, f3 g) {
+    PackedVertex p;
+    p.a = brdf_grad(v.cL, v.dfLdr, v.bW * g);
+    f3 Q = (v.bpq * g) * v.c;
+    float r = (v.c > 0.0f) ? v.dfdr * rcp(v.c) : 0.0f;
+    p.b = make_float4(Q.x, Q.y, Q.z, r);
+    p.c = make_float4(v.T.x, v.T.y, v.T.z, v.uv.x);
+    p.d = make_float4(v.fLW.x, v.fLW.y, v.fLW.z, v.uv.y);
+    return p;
+}
+
+// One step of the adjoint sweep (prb.py:105-187, corrected weight App. B-3): consumes a vertex,
 // carries Li one vertex towards the camera and returns that vertex's material gradient.
-ZD float4 sweep_vertex(const PathVertex &v, f3 &Li, f3 le_grad) {
-    f3 ctL = v.bW * le_grad;
-    f3 ct = (v.bpq * Li) * le_grad;
-    float4 a = brdf_grad(v.cL, v.dfLdr, ctL), b = brdf_grad(v.c, v.dfdr, ct);
-    Li = v.fLW + v.T * Li;
-    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+ZD float4 sweep_vertex(const PackedVertex &p, f3 &Li, f2 &uv) {
+    f3 ct = mk3(p.b.x, p.b.y, p.b.z) * Li;
+    float4 g = make_float4(p.a.x + ct.x, p.a.y + ct.y, p.a.z + ct.z, p.a.w + p.b.w * (ct.x + ct.y + ct.z));
+    Li = mk3(p.d.x, p.d.y, p.d.z) + mk3(p.c.x, p.c.y, p.c.z) * Li;
+    uv.x = p.c.w; uv.y = p.d.w;
+    return g;
 }

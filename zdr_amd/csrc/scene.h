@@ -86,7 +86,9 @@ ZD float4 read_bsdf(const float4 *__restrict__ mat, f2 uv, int tex_h, int tex_w)
 //  * Per-wavefront LDS queue, transposed flush.  Lanes push (cell, g, ox, oy); on flush 16 lanes
 //    serve one vertex (lane j adds float j of the cell), so a wave instruction carries four whole
 //    64-byte cells instead of 64 unrelated dwords: one atomic request per vertex instead of 16.
-#define ZDR_SCATTER_CAP 128          // queue entries per wavefront (7 dwords each)
+#ifndef ZDR_SCATTER_CAP
+#define ZDR_SCATTER_CAP 64           // queue entries per wavefront (7 dwords each)
+#endif
 
 struct ScatterQueue {                // pointers into this wave's LDS block
     int *cell; float *g; float *ox; float *oy;

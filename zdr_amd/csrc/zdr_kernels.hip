@@ -10,7 +10,7 @@
 
 #define WAVE 64
 #ifndef ZDR_MIN_WAVES
-#define ZDR_MIN_WAVES 1
+#define ZDR_MIN_WAVES 4   // <=128 VGPRs: 4 waves per SIMD measured best (profiles/r1_ab_flags.txt)
 #endif
 
 struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk; };
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
     Counters cnt;
 #pragma unroll
     for (int i = 0; i < 8; i++) cnt.c[i] = 0;
-    PathVertex *rec = nullptr; int nrec = 0; f3 term_Li = mk3(0.0f);
+    PathVertex pv; bool has_vertex; f3 term_Li = mk3(0.0f);
     f3 sum = mk3(0.0f);
     uint32_t it = w.s_begin;
     bool alive = false;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
         }
         if (__ballot(alive) == 0ull) break;                 // every lane has exhausted its samples
         if (alive) {
-            bool done = path_bounce<SK, A, false, STATS>(S, R, C, io, lds, ps, rec, nrec, term_Li, cnt);
+            bool done = path_bounce<SK, A, false, STATS>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt);
             if (done) {
                 alive = false;
                 if (!any_nan(ps.L)) sum = sum + clamp_radiance(ps.L);   // integrator.py:27-28
@@ -107,58 +107,73 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
     flush_counters<STATS>(io, cnt);
 }
 
-// PRB backward as a software pipeline.  Each trip a lane (1) advances its current path by one
-// bounce, recording the shaded vertex, and (2) sweeps up to two vertices of its PREVIOUS path
-// (last to first, carrying Li), queueing their gradients.  Records ping-pong between two
-// per-lane buffers (scratch); a finished path waits only while the sweeper still holds the other
-// buffer.  All queue traffic happens at reconverged points so the whole wave takes part in a flush.
+// PRB backward with ONE traversal.  Each trip a live lane advances its path by one bounce and
+// appends the shaded vertex (64 packed bytes) to its record list: the first ZDR_LDS_VERTICES
+// vertices live in LDS laid out [slot][float4][lane] (conflict-free ds_*_b128), deeper ones (5 % of
+// all vertices on cbox) in per-lane scratch.  When a path ends, a short wave-uniform loop sweeps its
+// records last to first (carrying Li) and queues the gradients; all queue traffic happens at
+// reconverged points so the whole wave takes part in a flush.  Keeping the records out of scratch is
+// what matters: 2.3 KB of scratch per lane thrashed L2 (113 GB of fabric traffic per launch, 13 of 37 ms).
+#ifndef ZDR_LDS_VERTICES
+#define ZDR_LDS_VERTICES 2
+#endif
 template <int SK, class A>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
+    __shared__ float4 lds_rec[ZDR_LDS_VERTICES * 4 * WAVE];
+    const int lane = threadIdx.x;
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     Counters cnt;
     const f3 le_grad = load_le_grad(C, io, w);
     ScatterQueue q = scatter_queue_init(lds_q);
-    PathVertex rec[2][ZDR_MAX_RECORDED_DEPTH];
-    int cur = 0, nrec = 0;
+    PackedVertex deep[ZDR_MAX_RECORDED_DEPTH - ZDR_LDS_VERTICES];
+    int nrec = 0;
     f3 term_Li = mk3(0.0f);
-    int sw_k = -1, sw_buf = 1;                              // sweeper: next vertex to consume, its buffer
+    int sw_k = -1;                                          // next vertex the sweep consumes
     f3 sw_Li = mk3(0.0f);
     uint32_t it = w.s_begin;
-    bool alive = false, waiting = false;
+    bool alive = false;
     PathState ps;
     ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
     ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
     for (;;) {
-        if (!alive && !waiting && w.valid && it < w.s_end) {
+        if (!alive && w.valid && it < w.s_end) {
             ps.smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
             pixel_ray<SK>(R, C, ps.smp, w.x, w.y, ps.o, ps.d);
             ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
             nrec = 0; term_Li = mk3(0.0f);
             alive = true; it++;
         }
-        if (__ballot(alive || waiting || sw_k >= 0) == 0ull) break;
+        if (__ballot(alive) == 0ull) break;
         if (alive) {
-            bool done = path_bounce<SK, A, true, false>(S, R, C, io, lds, ps, rec[cur], nrec, term_Li, cnt);
-            if (done) { alive = false; waiting = true; }
-        }
-        if (waiting && sw_k < 0) {                          // hand the finished path to the sweeper
-            waiting = false;
-            if (!any_nan(ps.L) && nrec > 0) {               // prb.py:100: NaN paths contribute nothing
-                sw_k = nrec - 1; sw_buf = cur; sw_Li = term_Li; cur ^= 1;
+            PathVertex pv; bool has_vertex;
+            bool done = path_bounce<SK, A, true, false>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt);
+            if (has_vertex) {
+                PackedVertex p = pack_vertex(pv, le_grad);
+                if (nrec < ZDR_LDS_VERTICES) {
+                    float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
+                    r[0] = p.a; r[WAVE] = p.b; r[2 * WAVE] = p.c; r[3 * WAVE] = p.d;
+                } else deep[nrec - ZDR_LDS_VERTICES] = p;
+                nrec++;
+            }
+            if (done) {
+                alive = false;
+                if (!any_nan(ps.L) && nrec > 0) { sw_k = nrec - 1; sw_Li = term_Li; }   // prb.py:100: NaN paths contribute nothing
             }
         }
-#pragma unroll
-        for (int rep = 0; rep < 2; rep++) {
+        while (__ballot(sw_k >= 0) != 0ull) {               // wave-uniform: sweep every finished path to its first vertex
             const bool sw = sw_k >= 0;
             float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             f2 guv; guv.x = 0.0f; guv.y = 0.0f;
             if (sw) {
-                PathVertex v = rec[sw_buf][sw_k];
-                g = sweep_vertex(v, sw_Li, le_grad);
-                guv = v.uv;
+                PackedVertex p;
+                if (sw_k < ZDR_LDS_VERTICES) {
+                    const float4 *r = lds_rec + (sw_k * 4) * WAVE + lane;
+                    p.a = r[0]; p.b = r[WAVE]; p.c = r[2 * WAVE]; p.d = r[3 * WAVE];
+                } else p = deep[sw_k - ZDR_LDS_VERTICES];
+                g = sweep_vertex(p, sw_Li, guv);
                 sw_k--;
             }
             scatter_push(q, io.cells, sw && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187

@@ -11,8 +11,8 @@
  *
  * Third-party pieces the reference gets from LuisaCompute (luisa-python,
  * unpinned, environment.yml:11-12) and that are restated from their published
- * behaviour: ray/triangle intersection (Moeller-Trumbore, two-sided,
- * tmin < t < tmax), Hit::interpolate ((1-u-v)a + ub + vc), offset_ray_origin
+ * behaviour: ray/triangle intersection (two-sided, tmin < t < tmax, evaluated
+ * in plane form — see tri_planes below), Hit::interpolate ((1-u-v)a + ub + vc), offset_ray_origin
  * (Waechter & Binder, Ray Tracing Gems ch. 6), reverse-mode autodiff of
  * ggx_brdf (hand-written tape below), float atomic add (here: float64 sums).
  */
@@ -61,7 +61,10 @@ struct zdro_scene {
     int light_count;
     int32_t *tri_inst;  /* instance of each triangle */
     v3 *wp;             /* ntris x 3 world-space corner positions */
+    float *planes;      /* ntris x 12: {n, n.p0} {nu, du} {nv, dv} (tri_planes) */
 };
+
+static void tri_planes(const v3 *p, float *out);
 
 static v3 xform_point(const float *m, v3 v) {
     /* (transform * float4(v, 1)).xyz — interaction.py:19-21 */
@@ -113,6 +116,7 @@ zdro_scene *zdro_scene_create(const float *verts, int nverts, const int32_t *tri
     s->light_insts = (int32_t *)malloc(sizeof(int32_t) * ninst);
     s->tri_inst = (int32_t *)malloc(sizeof(int32_t) * (size_t)ntris);
     s->wp = (v3 *)malloc(sizeof(v3) * 3 * (size_t)ntris);
+    s->planes = (float *)malloc(sizeof(float) * 12 * (size_t)ntris);
     for (int i = 0; i < ninst; i++) {
         normal_matrix(s->xform + 16 * i, s->nmat + 9 * i);
         for (int t = s->tri_begin[i]; t < s->tri_begin[i + 1]; t++) {
@@ -121,6 +125,7 @@ zdro_scene *zdro_scene_create(const float *verts, int nverts, const int32_t *tri
                 const float *v = s->verts + 8 * (size_t)s->tris[3 * (size_t)t + k];
                 s->wp[3 * (size_t)t + k] = xform_point(s->xform + 16 * i, V3(v[0], v[1], v[2]));
             }
+            tri_planes(s->wp + 3 * (size_t)t, s->planes + 12 * (size_t)t);
         }
     }
     rebuild_lights(s);
@@ -130,7 +135,7 @@ zdro_scene *zdro_scene_create(const float *verts, int nverts, const int32_t *tri
 void zdro_scene_destroy(zdro_scene *s) {
     if (!s) return;
     free(s->verts); free(s->tris); free(s->tri_begin); free(s->xform); free(s->nmat);
-    free(s->emission); free(s->light_insts); free(s->tri_inst); free(s->wp); free(s);
+    free(s->emission); free(s->light_insts); free(s->tri_inst); free(s->wp); free(s->planes); free(s);
 }
 
 void zdro_scene_set_emissions(zdro_scene *s, const float *e) {
@@ -142,21 +147,35 @@ void zdro_scene_set_emissions(zdro_scene *s, const float *e) {
 typedef struct { v3 o; float tmin; v3 d; float tmax; } ray_t;
 typedef struct { int inst, prim; float u, v, t; } hit_t; /* inst < 0: miss */
 
-static inline int tri_intersect(const v3 *p, const ray_t *r, float tmax, float *t, float *u, float *v) {
-    /* Moeller-Trumbore, two-sided; accepts tmin < t < tmax */
-    v3 e1 = vsub(p[1], p[0]), e2 = vsub(p[2], p[0]);
-    v3 pv = vcross(r->d, e2);
-    float det = vdot(e1, pv);
-    if (det == 0.0f) return 0;
-    float inv = 1.0f / det;
-    v3 tv = vsub(r->o, p[0]);
-    float uu = vdot(tv, pv) * inv;
-    if (!(uu >= 0.0f && uu <= 1.0f)) return 0;
-    v3 qv = vcross(tv, e1);
-    float vv = vdot(r->d, qv) * inv;
-    if (!(vv >= 0.0f && uu + vv <= 1.0f)) return 0;
-    float tt = vdot(e2, qv) * inv;
+/* Ray/triangle test in plane form (Havel & Herout 2010 style).  Per triangle, from the float32
+ * world-space corners, in float64 and rounded once to float32:
+ *   n = e1 x e2,  N = (n, n.p0)            t = (N.w - n.o) / (n.d)
+ *   nu = (e2 x n) / |n|^2, du = -nu.p0     u = nu.p + du      with p = o + t d
+ *   nv = (n x e1) / |n|^2, dv = -nv.p0     v = nv.p + dv
+ * Two-sided; a hit needs tmin < t < tmax, u >= 0, v >= 0, u + v <= 1.  LuisaCompute's own
+ * intersector (OptiX on its cuda backend) is third-party and unpinned; this is its restatement. */
+static void tri_planes(const v3 *p, float *out) {
+    double p0[3] = {p[0].x, p[0].y, p[0].z};
+    double e1[3] = {(double)p[1].x - p0[0], (double)p[1].y - p0[1], (double)p[1].z - p0[2]};
+    double e2[3] = {(double)p[2].x - p0[0], (double)p[2].y - p0[1], (double)p[2].z - p0[2]};
+    double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    double nu[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
+    double nv[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
+    out[0] = (float)n[0]; out[1] = (float)n[1]; out[2] = (float)n[2]; out[3] = (float)(n[0] * p0[0] + n[1] * p0[1] + n[2] * p0[2]);
+    out[4] = (float)nu[0]; out[5] = (float)nu[1]; out[6] = (float)nu[2]; out[7] = (float)-(nu[0] * p0[0] + nu[1] * p0[1] + nu[2] * p0[2]);
+    out[8] = (float)nv[0]; out[9] = (float)nv[1]; out[10] = (float)nv[2]; out[11] = (float)-(nv[0] * p0[0] + nv[1] * p0[1] + nv[2] * p0[2]);
+}
+
+static inline int tri_intersect(const float *q, const ray_t *r, float tmax, float *t, float *u, float *v) {
+    float nd = q[0] * r->d.x + q[1] * r->d.y + q[2] * r->d.z;
+    float tn = q[3] - (q[0] * r->o.x + q[1] * r->o.y + q[2] * r->o.z);
+    float tt = tn / nd;
     if (!(tt > r->tmin && tt < tmax)) return 0;
+    v3 p = vadd(r->o, vscale(r->d, tt));
+    float uu = q[4] * p.x + q[5] * p.y + q[6] * p.z + q[7];
+    float vv = q[8] * p.x + q[9] * p.y + q[10] * p.z + q[11];
+    if (!(uu >= 0.0f && vv >= 0.0f && uu + vv <= 1.0f)) return 0;
     *t = tt; *u = uu; *v = vv;
     return 1;
 }
@@ -165,7 +184,7 @@ static hit_t trace_closest(const zdro_scene *s, const ray_t *r) {
     hit_t h; h.inst = -1; h.prim = -1; h.u = h.v = 0; h.t = r->tmax;
     for (int t = 0; t < s->ntris; t++) {
         float tt, u, v;
-        if (tri_intersect(s->wp + 3 * (size_t)t, r, h.t, &tt, &u, &v)) {
+        if (tri_intersect(s->planes + 12 * (size_t)t, r, h.t, &tt, &u, &v)) {
             h.t = tt; h.u = u; h.v = v; h.inst = s->tri_inst[t]; h.prim = t - s->tri_begin[h.inst];
         }
     }
@@ -175,7 +194,7 @@ static hit_t trace_closest(const zdro_scene *s, const ray_t *r) {
 static int trace_any(const zdro_scene *s, const ray_t *r) {
     for (int t = 0; t < s->ntris; t++) {
         float tt, u, v;
-        if (tri_intersect(s->wp + 3 * (size_t)t, r, r->tmax, &tt, &u, &v)) return 1;
+        if (tri_intersect(s->planes + 12 * (size_t)t, r, r->tmax, &tt, &u, &v)) return 1;
     }
     return 0;
 }

@@ -36,7 +36,21 @@ def image_diff_stats(got, ref):
 FLOOR_FACTORS = {"frac_bad": 2.0, "mean_rel": 2.0, "rel_l1": 2.0, "sum_rel": 6.0}
 
 
-def assert_image_parity(got, ref, what, floor=None, frac_bad=2e-3, mean_rel=2e-5, sum_rel=1e-5):
+MAX_FLIPPED_PATHS = 20
+
+
+def _flip_allowance(n_paths, numel, entries_per_path):
+    """A path whose branch flipped in the last ulp (another triangle, RR survival, lobe choice) changes
+    its own contribution completely.  In a render of n_paths paths at most MAX_FLIPPED_PATHS such paths
+    are tolerated: each moves 1/n_paths of the total and touches entries_per_path tensor entries.
+    Irrelevant (below the base bars) for anything but tiny test renders."""
+    if not n_paths:
+        return {"frac_bad": 0.0, "mean_rel": 0.0, "rel_l1": 0.0, "sum_rel": 0.0}
+    f = MAX_FLIPPED_PATHS / float(n_paths)
+    return {"frac_bad": MAX_FLIPPED_PATHS * entries_per_path / float(numel), "mean_rel": f, "rel_l1": f, "sum_rel": f}
+
+
+def assert_image_parity(got, ref, what, floor=None, frac_bad=2e-3, mean_rel=2e-5, sum_rel=1e-5, n_paths=None):
     """Stated fp32 tolerance of the forward image (BASELINE.json north_star: 'within a stated fp32
     tolerance').  Base bar: at most 0.2 % of the values differ by more than 1e-4 (1 + |ref|) — samples
     whose path took another branch because a comparison flipped in the last ulp — the mean absolute
@@ -49,8 +63,9 @@ def assert_image_parity(got, ref, what, floor=None, frac_bad=2e-3, mean_rel=2e-5
     st = image_diff_stats(got, ref)
     fl = image_diff_stats(floor, ref) if floor is not None else None
     print(f"[parity] {what}: {st}" + (f" | fp32 floor (oracle fma vs ieee): {fl}" if fl else ""))
+    allow = _flip_allowance(n_paths, np.asarray(ref).size, 3)
     for key, base in (("frac_bad", frac_bad), ("mean_rel", mean_rel), ("sum_rel", sum_rel)):
-        bound = max(base, FLOOR_FACTORS[key] * fl[key]) if fl else base
+        bound = (max(base, FLOOR_FACTORS[key] * fl[key]) if fl else base) + allow[key]
         assert st[key] <= bound, (what, key, st, fl)
     return st
 
@@ -67,15 +82,16 @@ def grad_diff_stats(got, ref):
     }
 
 
-def assert_grad_parity(got, ref, what, floor=None, frac_bad=2e-3, rel_l1=2e-4, sum_rel=1e-4):
+def assert_grad_parity(got, ref, what, floor=None, frac_bad=2e-3, rel_l1=2e-4, sum_rel=1e-4, n_paths=None):
     """Stated fp32 tolerance of the gradient texture: float atomics accumulate in arrival order (the
     oracle sums in float64) and a rare branch flip moves one path's contribution.  `floor` as in
     assert_image_parity: the gradient of the fma-contracted oracle build calibrates the bounds."""
     st = grad_diff_stats(got, ref)
     fl = grad_diff_stats(floor, ref) if floor is not None else None
     print(f"[parity] {what}: {st}" + (f" | fp32 floor (oracle fma vs ieee): {fl}" if fl else ""))
+    allow = _flip_allowance(n_paths, np.asarray(ref).size, 64)   # <= 16 vertices x 4 texels ... typically 2-3 vertices x 16 floats
     for key, base in (("frac_bad", frac_bad), ("rel_l1", rel_l1), ("sum_rel", sum_rel)):
-        bound = max(base, FLOOR_FACTORS[key] * fl[key]) if fl else base
+        bound = (max(base, FLOOR_FACTORS[key] * fl[key]) if fl else base) + allow[key]
         assert st[key] <= bound, (what, key, st, fl)
     return st
 

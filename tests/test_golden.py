@@ -56,8 +56,8 @@ def test_hip_matches_golden(case, cbox_arrays):
     Sf = oracle.OracleScene.from_arrays(cbox_arrays, variant="fma")
     p = oracle.make_params(integ, W, W, spp, seed, CBOX_CAMERA, mat.shape[:2], use_tent=tent)
     pb = oracle.make_params(integ, W, W, spp, seed + 1, CBOX_CAMERA, mat.shape[:2], use_tent=tent)
-    assert_image_parity(img.detach().cpu().numpy()[..., :3], G[name + "/image"][..., :3], "golden " + name, floor=Sf.render_forward(p, mat)[..., :3])
-    assert_grad_parity(m.grad.cpu().numpy(), G[name + "/grad"], "golden grad " + name, floor=Sf.render_backward(pb, np.ones((W, W, 4), np.float32), mat))
+    assert_image_parity(img.detach().cpu().numpy()[..., :3], G[name + "/image"][..., :3], "golden " + name, floor=Sf.render_forward(p, mat)[..., :3], n_paths=W * W * spp)
+    assert_grad_parity(m.grad.cpu().numpy(), G[name + "/grad"], "golden grad " + name, floor=Sf.render_backward(pb, np.ones((W, W, 4), np.float32), mat), n_paths=W * W * spp)
 
 
 @pytest.mark.gpu

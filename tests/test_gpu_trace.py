@@ -23,12 +23,13 @@ def check_closest(scene, S, rays, what):
     same_prim = (ip[both] == rip[both]).all(axis=1)
     assert (~same_prim).mean() < 2e-4          # exact ties on shared edges may pick the neighbour
     ok = both.copy(); ok[both] = same_prim
-    # the GPU uses v_rcp_f32 (1 ulp) for 1/det: near-parallel rays (tiny det) amplify that, so the
-    # tight bound is required of >= 99.98 % of the rays and a looser one of every ray
-    terr = np.abs(bt[ok, 2] - rbt[ok, 2]) / (1e-6 + np.abs(rbt[ok, 2]))
+    # t = (n.p0 - n.o) / (n.d): the numerator cancels, so its error is ABSOLUTE — about one ulp of the
+    # scene coordinates (|p| ~ 10 -> 1e-6) — on top of the 1-ulp v_rcp_f32.  Bound the hit-point error
+    # accordingly: |dt| <= 1e-5 |t| + 5e-6 for >= 99.98 % of the rays, 50x that for every ray.
+    terr = np.abs(bt[ok, 2] - rbt[ok, 2]) / (1e-5 * np.abs(rbt[ok, 2]) + 5e-6)
     berr = np.abs(bt[ok, :2] - rbt[ok, :2]).max(axis=1)
-    assert (terr > 1e-5).mean() < 2e-4 and terr.max() < 1e-3, (terr.max(), (terr > 1e-5).mean())
-    assert (berr > 2e-5).mean() < 2e-4 and berr.max() < 2e-3, (berr.max(), (berr > 2e-5).mean())
+    assert (terr > 1).mean() < 2e-4 and terr.max() < 50, (terr.max(), (terr > 1).mean())
+    assert (berr > 1e-4).mean() < 2e-4 and berr.max() < 5e-3, (berr.max(), (berr > 1e-4).mean())
 
 
 @pytest.mark.parametrize("accel", ["brute", "bvh"])

@@ -3,7 +3,7 @@
 //    so triangle data arrives through scalar loads into SGPRs and costs no VGPRs or LDS.
 //  * BvhAccel: BVH2 with a per-lane traversal stack in LDS laid out [entry][lane] (one bank per
 //    lane, conflict-free), 64-byte nodes and 48-byte triangles fetched with dwordx4 loads.
-// Both run the same two-sided Moeller-Trumbore test accepting tmin < t < tmax, so they return
+// Both run the same two-sided plane-form triangle test accepting tmin < t < tmax, so they return
 // the same hit (up to exact ties in t).
 #pragma once
 #include "scene.h"
@@ -22,19 +22,28 @@ typedef const v4f __attribute__((address_space(4))) *const_v4f_ptr;
 ZD const_v4f_ptr as_constant(const float4 *p) { return (const_v4f_ptr)(uintptr_t)p; }
 ZD float4 f4(v4f a) { return make_float4(a.x, a.y, a.z, a.w); }
 
-ZD bool tri_test(float4 a, float4 b, float4 c, f3 o, f3 d, float tmin, float tmax, float &t, float &u, float &v) {
-    f3 v0 = xyz(a), e1 = xyz(b), e2 = xyz(c);
-    f3 pv = cross(d, e2);
-    float det = dot(e1, pv);
-    float inv = rcp(det);
-    f3 tv = o - v0;
-    float uu = dot(tv, pv) * inv;
-    f3 qv = cross(tv, e1);
-    float vv = dot(d, qv) * inv;
-    float tt = dot(e2, qv) * inv;
-    bool ok = (det != 0.0f) & (uu >= 0.0f) & (uu <= 1.0f) & (vv >= 0.0f) & (uu + vv <= 1.0f) & (tt > tmin) & (tt < tmax);
-    t = tt; u = uu; v = vv;
-    return ok;
+// Plane-form ray/triangle test (Havel & Herout style).  isect[3 slot + {0,1,2}] = N {n, n.p0},
+// U {nu, du}, V {nv, dv}, precomputed in float64 on the host (zdr_api.cpp):
+//   t = (N.w - n.o) / (n.d),  p = o + t d,  u = nu.p + du,  v = nv.p + dv,  hit: tmin < t < tmax, u, v >= 0, u + v <= 1
+// 26 VALU per triangle against 46 for Moeller-Trumbore with precomputed edges; the closest-hit loops
+// track only (t, slot) and evaluate the barycentrics of the winner once, after the loop.
+ZD bool tri_test(float4 N, float4 U, float4 V, f3 o, f3 d, float tmin, float tmax, float &t) {
+    float nd = N.x * d.x + N.y * d.y + N.z * d.z;
+    float tn = N.w - (N.x * o.x + N.y * o.y + N.z * o.z);
+    float tt = tn * rcp(nd);
+    f3 p = o + d * tt;
+    float uu = U.x * p.x + U.y * p.y + U.z * p.z + U.w;
+    float vv = V.x * p.x + V.y * p.y + V.z * p.z + V.w;
+    t = tt;
+    return (tt > tmin) & (tt < tmax) & (uu >= 0.0f) & (vv >= 0.0f) & (uu + vv <= 1.0f);
+}
+
+ZD void hit_barycentrics(const DScene &S, Hit &h, f3 o, f3 d) {
+    if (h.slot < 0) return;
+    float4 U = S.isect[3 * (size_t)h.slot + 1], V = S.isect[3 * (size_t)h.slot + 2];
+    f3 p = o + d * h.t;
+    h.u = U.x * p.x + U.y * p.y + U.z * p.z + U.w;
+    h.v = V.x * p.x + V.y * p.y + V.z * p.z + V.w;
 }
 
 struct BruteAccel {
@@ -44,10 +53,11 @@ struct BruteAccel {
         const_v4f_ptr tri = as_constant(S.isect);
 #pragma unroll ZDR_TRI_UNROLL
         for (int s = 0; s < S.ntris; s++) {
-            float t, u, v;
-            bool ok = tri_test(f4(tri[3 * s]), f4(tri[3 * s + 1]), f4(tri[3 * s + 2]), o, d, tmin, h.t, t, u, v);
-            h.t = ok ? t : h.t; h.u = ok ? u : h.u; h.v = ok ? v : h.v; h.slot = ok ? s : h.slot;
+            float t;
+            bool ok = tri_test(f4(tri[3 * s]), f4(tri[3 * s + 1]), f4(tri[3 * s + 2]), o, d, tmin, h.t, t);
+            h.t = ok ? t : h.t; h.slot = ok ? s : h.slot;
         }
+        hit_barycentrics(S, h, o, d);
         return h;
     }
     ZD static bool any(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
@@ -55,8 +65,8 @@ struct BruteAccel {
         const_v4f_ptr tri = as_constant(S.isect);
 #pragma unroll ZDR_TRI_UNROLL
         for (int s = 0; s < S.ntris; s++) {
-            float t, u, v;
-            occ |= tri_test(f4(tri[3 * s]), f4(tri[3 * s + 1]), f4(tri[3 * s + 2]), o, d, tmin, tmax, t, u, v);
+            float t;
+            occ |= tri_test(f4(tri[3 * s]), f4(tri[3 * s + 1]), f4(tri[3 * s + 2]), o, d, tmin, tmax, t);
         }
         return occ;
     }
@@ -103,9 +113,9 @@ struct BvhAccel {
                 else if (h1) { id = c1; cnt = k1; continue; }
             } else {
                 for (int s = id; s < id + cnt; s++) {
-                    float t, u, v;
-                    bool ok = tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, h.t, t, u, v);
-                    if (ok) { h.t = t; h.u = u; h.v = v; h.slot = s; }
+                    float t;
+                    bool ok = tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, h.t, t);
+                    if (ok) { h.t = t; h.slot = s; }
                 }
                 if (ANY && h.slot >= 0) return h;
             }
@@ -114,6 +124,7 @@ struct BvhAccel {
             int e = stack[sp * 64 + lane];
             id = e >> 3; cnt = e & 7;
         }
+        if (!ANY) hit_barycentrics(S, h, o, d);
         return h;
     }
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {

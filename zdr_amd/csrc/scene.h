@@ -7,7 +7,7 @@
 #define ZDR_BVH_STACK 48   // per-lane traversal stack entries; the builder bounds the tree depth below it
 
 // Per-slot records, 16-byte aligned so a record is fetched with dwordx4 loads:
-//   isect[3*slot + {0,1,2}] = {v0.xyz,0} {e1.xyz,0} {e2.xyz,0}         (48 B, traversal)
+//   isect[3*slot + {0,1,2}] = {n, n.p0} {nu, du} {nv, dv}              (48 B, plane-form triangle test)
 //   shade[8*slot + ...]     = one 128-byte line:                       (surface_interact, lights)
 //     r0 {p0.xyz, uv0.x} r1 {p1.xyz, uv0.y} r2 {p2.xyz, uv1.x}
 //     r3 {n0.xyz, uv1.y} r4 {n1.xyz, uv2.x} r5 {n2.xyz, uv2.y}   n_i = inverse-transpose(M) * vn_i

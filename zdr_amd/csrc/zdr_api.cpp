@@ -244,10 +244,18 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     for (uint32_t slot = 0; slot < ntris; slot++) {
         const TriRec &r = rec[order[slot]];
         slot_of_tri[order[slot]] = (int32_t)slot;
-        h3 e1 = hsub(r.p[1], r.p[0]), e2 = hsub(r.p[2], r.p[0]);
-        isect[3 * (size_t)slot + 0] = make_float4(r.p[0].x, r.p[0].y, r.p[0].z, 0.0f);
-        isect[3 * (size_t)slot + 1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
-        isect[3 * (size_t)slot + 2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+        {   // plane-form intersection record, float64 -> float32 (accel.h, tri_test)
+            double p0[3] = {r.p[0].x, r.p[0].y, r.p[0].z};
+            double e1[3] = {(double)r.p[1].x - p0[0], (double)r.p[1].y - p0[1], (double)r.p[1].z - p0[2]};
+            double e2[3] = {(double)r.p[2].x - p0[0], (double)r.p[2].y - p0[1], (double)r.p[2].z - p0[2]};
+            double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+            double nu[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
+            double nv[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
+            isect[3 * (size_t)slot + 0] = make_float4((float)n[0], (float)n[1], (float)n[2], (float)(n[0] * p0[0] + n[1] * p0[1] + n[2] * p0[2]));
+            isect[3 * (size_t)slot + 1] = make_float4((float)nu[0], (float)nu[1], (float)nu[2], (float)-(nu[0] * p0[0] + nu[1] * p0[1] + nu[2] * p0[2]));
+            isect[3 * (size_t)slot + 2] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], (float)-(nv[0] * p0[0] + nv[1] * p0[1] + nv[2] * p0[2]));
+        }
         float4 *q = &shade[8 * (size_t)slot];
         q[0] = make_float4(r.p[0].x, r.p[0].y, r.p[0].z, r.uv[0][0]);
         q[1] = make_float4(r.p[1].x, r.p[1].y, r.p[1].z, r.uv[0][1]);

@@ -57,7 +57,7 @@ typedef struct {
 typedef struct {
     uint32_t ntris, nverts, ninst, light_count;
     int32_t accel;                     /* ZDR_ACCEL_BRUTE or ZDR_ACCEL_BVH actually in use */
-    uint32_t bvh_nodes, bvh_max_depth;
+    uint32_t bvh_nodes, bvh_max_depth, bvh_stack_entries;   /* BVH4 nodes, depth of the binary SAH tree, LDS stack entries per lane */
     int32_t device;
     uint64_t device_bytes;             /* HBM held by the scene */
 } zdr_scene_info_t;
@@ -121,6 +121,14 @@ int zdr_trace_any(zdr_scene *scene, const float *rays, uint32_t n, int32_t *occl
  * (SURVEY App. A.8); unused slots are 0. */
 int zdr_sampler_dump(zdr_scene *scene, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries,
                      uint32_t n, int32_t nvert, int32_t rr_depth, float *out, void *stream);
+
+/* Host-only: builds the acceleration structure exactly as zdr_scene_create does and returns it,
+ * without touching a GPU, so that the CPU test-suite can run an emulation of the device traversal
+ * on the very data the kernels read (tests/test_bvh_emulation.py).  tri_xyz: ntris x 9 world-space
+ * corners.  nodes_out: nodes_cap x 32 floats (BVH4 node = 128 bytes, layout in csrc/scene.h);
+ * order_out[slot] = input triangle; isect_out: ntris x 12 floats (plane-form records, slot order). */
+int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int accel, float *nodes_out, uint32_t nodes_cap,
+                          uint32_t *nnodes, uint32_t *stack_entries, int32_t *order_out, float *isect_out);
 
 #ifdef __cplusplus
 }

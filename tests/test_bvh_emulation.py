@@ -1,0 +1,175 @@
+"""CPU emulation of the DEVICE traversal (csrc/accel.h, BvhAccel::traverse) on the node / triangle
+arrays the host builder produces (zdr_debug_build_accel, no GPU involved), checked against the
+oracle's brute force.  This is the executable spec of the traversal: change accel.h and this file
+together.  It exists because a traversal bug on the GPU is a hang, not a failed assert."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import cbox_models
+from zdr_amd import _native, geometry
+
+
+
+def world_triangles(A):
+    out = np.zeros((A.tris.shape[0], 3, 3), np.float32)
+    for i in range(A.ninst):
+        M = A.inst_xform[i].reshape(4, 4)
+        for t in range(A.inst_tri_begin[i], A.inst_tri_begin[i + 1]):
+            for k in range(3):
+                v = A.verts[A.tris[t, k], :3]
+                out[t, k] = [M[r, 0] * v[0] + M[r, 1] * v[1] + M[r, 2] * v[2] + M[r, 3] for r in range(3)]
+    return out
+
+
+def build(A, accel):
+    tri = np.ascontiguousarray(world_triangles(A).reshape(-1, 9))
+    n = tri.shape[0]
+    nodes = np.zeros((max(n, 8), 32), np.float32)
+    order = np.zeros(n, np.int32); isect = np.zeros((n, 12), np.float32); nn = C.c_uint32(); se = C.c_uint32()
+    rc = _native.lib().zdr_debug_build_accel(tri.ctypes.data, n, accel, nodes.ctypes.data, nodes.shape[0], C.byref(nn), C.byref(se), order.ctypes.data, isect.ctypes.data)
+    assert rc == 0, _native.lib().zdr_last_error()
+    global STACK
+    STACK = se.value                          # what the kernels allocate in LDS for this tree
+    assert 8 <= STACK <= 48 and STACK % 4 == 0
+    return nodes[:nn.value], order, isect
+
+
+def tri_test(q, o, d, tmin, tmax):
+    f = np.float32
+    nd = f(q[0] * d[0] + q[1] * d[1] + q[2] * d[2])
+    tn = f(q[3] - f(q[0] * o[0] + q[1] * o[1] + q[2] * o[2]))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = f(tn / nd)
+    p = o + d * t
+    u = f(q[4] * p[0] + q[5] * p[1] + q[6] * p[2] + q[7]); v = f(q[8] * p[0] + q[9] * p[1] + q[10] * p[2] + q[11])
+    return bool(t > tmin and t < tmax and u >= 0 and v >= 0 and u + v <= 1), t
+
+
+def box_entry(lo, hi, o, inv, tmin, tmax):
+    with np.errstate(invalid="ignore", over="ignore"):
+        t0 = (lo - o) * inv; t1 = (hi - o) * inv
+    tn = max(np.fmax.reduce(np.fmin(t0, t1)), tmin)      # fmin/fmax drop NaNs like v_min_f32 / v_max_f32
+    tf = min(np.fmin.reduce(np.fmax(t0, t1)), tmax)
+    return tn if tn <= tf else 3.0e38
+
+
+def traverse(nodes, isect, o, d, tmin, tmax, any_hit):
+    """line-by-line mirror of BvhAccel::traverse<ANY>"""
+    ntris, nnodes = isect.shape[0], nodes.shape[0]
+    best_t, slot = np.float32(tmax), -1
+    with np.errstate(divide="ignore"):
+        inv = np.float32(1.0) / d
+    stack = []
+    nid, cnt = 0, (ntris if nnodes == 0 else 0)
+    budget = 2 * (nnodes + ntris) + 8
+    steps = 0
+    while True:
+        budget -= 1
+        if budget < 0:
+            raise AssertionError("watchdog fired: the walk visited something twice")
+        steps += 1
+        descended = False
+        if cnt == 0:
+            n = nodes[nid]
+            lo = np.stack([n[0:4], n[4:8], n[8:12]], 1); hi = np.stack([n[12:16], n[16:20], n[20:24]], 1)
+            child = n[24:28].view(np.int32); k = n[28:32].view(np.int32)
+            e = [box_entry(lo[c], hi[c], o, inv, tmin, best_t) if k[c] >= 0 else 3.0e38 for c in range(4)]
+            p = [(int(child[c]) << 3) | int(k[c]) for c in range(4)]
+            em = min(e)
+            if em < 2.0e38:
+                nxt, taken = -1, [False] * 4
+                for c in range(4):
+                    if nxt < 0 and e[c] == em:
+                        nxt, taken[c] = p[c], True
+                assert len(stack) + 4 <= STACK        # the device stores four slots unconditionally
+                for c in range(4):
+                    if not taken[c] and e[c] < 2.0e38:
+                        stack.append(p[c])
+                if nxt >= 0:
+                    nid, cnt = nxt >> 3, nxt & 7
+                    descended = True
+        else:
+            for s in range(nid, nid + cnt):
+                ok, t = tri_test(isect[s], o, d, tmin, best_t)
+                if ok:
+                    best_t, slot = t, s
+            if any_hit and slot >= 0:
+                return slot, best_t, steps
+        if descended:
+            continue
+        if not stack:
+            break
+        e = stack.pop()
+        nid, cnt = e >> 3, e & 7
+    return slot, best_t, steps
+
+
+def rays_for(lo, hi, n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+def check_scene(A, lo, hi, nrays, seed):
+    nodes, order, isect = build(A, _native.ACCEL_BVH)
+    # structure: leaves tile the slots, order is a permutation
+    assert sorted(order.tolist()) == list(range(A.tris.shape[0]))
+    S = oracle.OracleScene.from_arrays(A)
+    o, d = rays_for(lo, hi, nrays, seed)
+    rays = np.zeros((nrays, 8), np.float32); rays[:, :3] = o; rays[:, 4:7] = d; rays[:, 7] = 1e30
+    rip, rbt = S.trace_closest(rays)
+    tri_inst = np.repeat(np.arange(A.ninst), np.diff(A.inst_tri_begin))
+    worst = 0
+    for i in range(nrays):
+        slot, t, steps = traverse(nodes, isect, o[i], d[i], np.float32(0), np.float32(1e30), False)
+        worst = max(worst, steps)
+        if rip[i, 0] < 0:
+            assert slot < 0, i
+        else:
+            assert slot >= 0, i
+            tri = order[slot]
+            same = tri_inst[tri] == rip[i, 0] and tri - A.inst_tri_begin[tri_inst[tri]] == rip[i, 1]
+            assert same or abs(t - rbt[i, 2]) < 1e-5 * (1 + abs(rbt[i, 2])), (i, tri, rip[i])   # ties on shared edges
+            assert abs(t - rbt[i, 2]) <= 1e-5 * abs(rbt[i, 2]) + 5e-6
+        # any-hit with a bounded ray agrees with the closest hit
+        tm = np.float32(0.7 * rbt[i, 2]) if rip[i, 0] >= 0 else np.float32(5.0)
+        s_any, _, _ = traverse(nodes, isect, o[i], d[i], np.float32(1e-4), tm, True)
+        occ = S.trace_any(np.concatenate([o[i], [1e-4], d[i], [tm]]).astype(np.float32)[None])[0]
+        assert (s_any >= 0) == bool(occ), i
+    return nodes.shape[0], worst
+
+
+def test_cbox_forced_bvh():
+    A = geometry.assemble(cbox_models())
+    nn, worst = check_scene(A, (-3, 0, -5.5), (2.5, 5.2, 6), 300, 1)
+    assert 1 <= nn <= 32 and worst <= 2 * (nn + 32)
+
+
+def test_terrain_bvh():
+    from gpu_util import terrain_arrays
+    A = terrain_arrays(n=14)                     # 394 triangles
+    nn, worst = check_scene(A, (-3, -0.5, -3), (3, 3.5, 3), 250, 2)
+    assert nn > 20
+
+
+def test_nan_and_axis_aligned_rays_terminate():
+    from gpu_util import terrain_arrays
+    A = terrain_arrays(n=10)
+    nodes, order, isect = build(A, _native.ACCEL_BVH)
+    for o, d in [((np.nan, 0, 0), (0, -1, 0)), ((0, 2, 0), (0, -1, 0)), ((0, 2, 0), (np.nan, np.nan, np.nan)),
+                 ((0.3, 2, 0.1), (1, 0, 0)), ((3, 0.0, 3), (-1, 0, 0)), ((np.inf, 0, 0), (1, 0, 0))]:
+        slot, t, steps = traverse(nodes, isect, np.array(o, np.float32), np.array(d, np.float32), np.float32(0), np.float32(1e30), False)
+        assert steps <= 2 * (nodes.shape[0] + isect.shape[0]) + 8
+
+
+def test_tiny_scene_is_a_single_leaf():
+    v = np.array([[0, 0, 0, 0, 0, 0, 1, 0], [1, 0, 0, 1, 0, 0, 1, 0], [0, 0, 1, 0, 1, 0, 1, 0]], np.float32)
+    A = geometry.from_arrays(v, np.array([[0, 2, 1]], np.int32))
+    nodes, order, isect = build(A, _native.ACCEL_BVH)
+    assert nodes.shape[0] == 0
+    slot, t, _ = traverse(nodes, isect, np.array([0.2, 1, 0.2], np.float32), np.array([0, -1, 0], np.float32), np.float32(0), np.float32(1e30), False)
+    assert slot == 0 and abs(t - 1) < 1e-6

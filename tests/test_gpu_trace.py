@@ -83,3 +83,36 @@ def test_large_bvh_any_is_consistent_with_closest():
     expect = hit & (t < torch.from_numpy(tmax).cuda())
     margin = (t - torch.from_numpy(tmax).cuda()).abs() > 1e-4          # ignore hits right at tmax
     assert ((occ != 0) == expect)[margin].all()
+
+
+def test_million_triangle_tessellated_cbox():
+    """BASELINE configs[4] at full size: size-independent properties (the oracle cannot brute-force 1M
+    triangles): any-hit agrees with closest-hit, the closed room has no holes, and the displaced,
+    tessellated room renders to (statistically) the same image as the 32-triangle room."""
+    from conftest import cbox_material_np
+    from zdr_amd import procedural
+    A = procedural.tessellated_cbox(cbox_models(), n=183, amplitude=0.004)
+    scene = make_scene("path", arrays=A)
+    info = scene.info()
+    assert info["ntris"] == 30 * 183 * 183 + 2 and info["accel"] == "bvh" and info["bvh_stack_entries"] <= 48
+    rng = np.random.default_rng(11)
+    n = 400000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform((-2.5, 0.3, -5.3), (2.0, 4.8, -0.8), (n, 3))
+    d = rng.standard_normal((n, 3)); rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); rays[:, 7] = 1e30
+    r = torch.from_numpy(rays).cuda()
+    ip, bt = scene.trace_closest(r)
+    # the room is closed except for the open front (+z): interior rays heading away from it always hit
+    inward = torch.from_numpy(rays[:, 6] < -0.2).cuda()
+    assert (ip[inward, 0] >= 0).float().mean().item() > 0.9999
+    tmax = torch.from_numpy(rng.uniform(0.05, 6.0, n).astype(np.float32)).cuda()
+    r2 = r.clone(); r2[:, 7] = tmax
+    occ = scene.trace_any(r2)
+    expect = (ip[:, 0] >= 0) & (bt[:, 2] < tmax)
+    margin = (bt[:, 2] - tmax).abs() > 1e-3
+    assert ((occ != 0) == expect)[margin].all()
+    m = torch.from_numpy(cbox_material_np()).cuda()
+    big = scene.render(m, res=(128, 128), spp=64, seed=1)[..., :3]
+    small = make_scene("path").render(m, res=(128, 128), spp=64, seed=1)[..., :3]
+    assert abs(big.mean().item() - small.mean().item()) / small.mean().item() < 0.03
+    assert not torch.isnan(big).any()

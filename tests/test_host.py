@@ -26,7 +26,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_native.CameraPOD) == 40
     assert C.sizeof(_native.RenderParams) == 4 * 15 + 40 + 8
     assert _native.RenderParams.camera.offset == 60 and _native.RenderParams.tex_h.offset == 100
-    assert C.sizeof(_native.SceneInfo) == 40
+    assert C.sizeof(_native.SceneInfo) == 48
 
 
 def test_no_silent_cpu_fallback():

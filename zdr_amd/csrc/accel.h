@@ -72,7 +72,7 @@ struct BruteAccel {
     }
 };
 
-// slab test against one child box; returns entry distance, or a value > tmax on a miss
+// slab test against one child box; returns entry distance, or 3e38 on a miss
 ZD float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float tmin, float tmax) {
     float t0x = (lox - o.x) * inv.x, t1x = (hix - o.x) * inv.x;
     float t0y = (loy - o.y) * inv.y, t1y = (hiy - o.y) * inv.y;
@@ -85,32 +85,49 @@ ZD float box_entry(float lox, float loy, float loz, float hix, float hiy, float 
 
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
-    // stack: this wave's LDS region, ZDR_BVH_STACK x 64 ints; entry e of lane l at stack[e * 64 + l]
+    // 4-wide BVH, one 128-byte node per visit (8 dwordx4 loads of one line), nearest hit child first.
+    // stack: this wave's LDS region, ZDR_BVH_STACK x 64 ints; entry e of lane l at stack[e * 64 + l].
+    // A work item is (id, cnt): cnt == 0 -> node id, cnt > 0 -> leaf slots [id, id + cnt); cnt < 0 -> unused child.
     template <bool ANY>
     ZD static Hit traverse(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
         const int lane = threadIdx.x & 63;
         f3 inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         int sp = 0;
-        // work item: (id, cnt): cnt == 0 -> inner node id, cnt > 0 -> leaf [id, id + cnt)
         int id = 0, cnt = (S.nnodes == 0) ? S.ntris : 0;
+        // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it
+        // impossible for a wave to spin forever whatever the node data or the ray (NaNs) look like.
+        int budget = 2 * (S.nnodes + S.ntris) + 8;
         for (;;) {
+            if (--budget < 0) break;
             if (cnt == 0) {
-                const float4 *n = S.nodes + 4 * (size_t)id;
-                float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-                float e0 = box_entry(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, tmin, h.t);
-                float e1 = box_entry(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, tmin, h.t);
-                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                int k0 = __float_as_int(n3.z), k1 = __float_as_int(n3.w);
-                bool h0 = e0 < 2.0e38f, h1 = e1 < 2.0e38f;
-                if (h0 & h1) {
-                    bool swap = e1 < e0;                      // nearer child first
-                    int fid = swap ? c0 : c1, fk = swap ? k0 : k1;
-                    id = swap ? c1 : c0; cnt = swap ? k1 : k0;
-                    if (sp < ZDR_BVH_STACK) { stack[sp * 64 + lane] = (fid << 3) | fk; sp++; }
+                const float4 *n = S.nodes + 8 * (size_t)id;
+                float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], ci = n[6], ck = n[7];
+                int k0 = __float_as_int(ck.x), k1 = __float_as_int(ck.y), k2 = __float_as_int(ck.z), k3 = __float_as_int(ck.w);
+                // cnt < 0 marks an unused child slot (a slab test cannot express "never hit": it takes
+                // min/max of the two plane distances, so an inverted box still passes)
+                float e0 = (k0 >= 0) ? box_entry(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, o, inv, tmin, h.t) : 3.0e38f;
+                float e1 = (k1 >= 0) ? box_entry(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, o, inv, tmin, h.t) : 3.0e38f;
+                float e2 = (k2 >= 0) ? box_entry(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, o, inv, tmin, h.t) : 3.0e38f;
+                float e3 = (k3 >= 0) ? box_entry(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, o, inv, tmin, h.t) : 3.0e38f;
+                int p0 = (__float_as_int(ci.x) << 3) | k0, p1 = (__float_as_int(ci.y) << 3) | k1;
+                int p2 = (__float_as_int(ci.z) << 3) | k2, p3 = (__float_as_int(ci.w) << 3) | k3;
+                // nearest child: visit now; the other hit children go on the stack.  The four stack
+                // writes are unconditional (LDS stores are cheap, branches are not): a slot is kept only
+                // if sp advances past it.  The builder guarantees sp + 4 <= ZDR_BVH_STACK here.
+                float em = fminf(fminf(e0, e1), fminf(e2, e3));
+                if (em < 2.0e38f) {
+                    bool t0 = (e0 == em), t1 = !t0 & (e1 == em), t2 = !(t0 | t1) & (e2 == em), t3 = !(t0 | t1 | t2);
+                    int next = t0 ? p0 : (t1 ? p1 : (t2 ? p2 : p3));
+                    int *sl = stack + sp * 64 + lane;
+                    sl[0] = p0; sl += (!t0 & (e0 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p1; sl += (!t1 & (e1 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p2; sl += (!t2 & (e2 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p3; sl += (!t3 & (e3 < 2.0e38f)) ? 64 : 0;
+                    sp = (int)((sl - (stack + lane)) >> 6);
+                    id = next >> 3; cnt = next & 7;
                     continue;
-                } else if (h0) { id = c0; cnt = k0; continue; }
-                else if (h1) { id = c1; cnt = k1; continue; }
+                }
             } else {
                 for (int s = id; s < id + cnt; s++) {
                     float t;

@@ -4,7 +4,7 @@
 #pragma once
 #include "vecmath.h"
 
-#define ZDR_BVH_STACK 48   // per-lane traversal stack entries; the builder bounds the tree depth below it
+#define ZDR_BVH_STACK 48   // upper bound of per-lane traversal stack entries; the builder bounds the tree depth below it
 
 // Per-slot records, 16-byte aligned so a record is fetched with dwordx4 loads:
 //   isect[3*slot + {0,1,2}] = {n, n.p0} {nu, du} {nv, dv}              (48 B, plane-form triangle test)
@@ -13,8 +13,9 @@
 //     r3 {n0.xyz, uv1.y} r4 {n1.xyz, uv2.x} r5 {n2.xyz, uv2.y}   n_i = inverse-transpose(M) * vn_i
 //     r6 {ng.xyz, area}                                          ng = normalize(cross(p1-p0, p2-p0))
 //     r7 {bits(inst), bits(prim), 0, 0}
-// BVH2 node (64 B): {lo0.xyz, hi0.x} {hi0.yz, lo1.xy} {lo1.z, hi1.xyz} {child0, child1, cnt0, cnt1}
-//   cnt == 0: child is a node index; cnt > 0: child is the first slot of a leaf of cnt triangles.
+// BVH4 node (128 B, one line): {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]} {child[4]} {cnt[4]}
+//   cnt == 0: child is a node index; cnt > 0: child is the first slot of a leaf of cnt triangles;
+//   an unused child has an inverted box.
 struct DScene {
     const float4 *isect;
     const float4 *shade;
@@ -24,6 +25,7 @@ struct DScene {
     const int32_t *inst_tri_begin;  // ninst + 1   (heap slot 23335 holds the counts)
     const int32_t *slot_of_tri;     // input triangle index -> slot
     int32_t ntris, ninst, light_count, nnodes;
+    int32_t stack_entries;          // per-lane traversal stack entries this tree needs (dynamic LDS: entries x 64 ints per wave)
 };
 
 struct Hit { int slot; float u, v, t; };   // slot < 0: miss (LuisaCompute Hit{inst, prim, bary, ray_t})

@@ -117,12 +117,129 @@ struct BvhBuilder {
     }
 };
 
+// plane-form intersection record of one triangle, float64 -> float32 (accel.h, tri_test)
+static void plane_record(const h3 *p, float4 *out) {
+    double p0[3] = {p[0].x, p[0].y, p[0].z};
+    double e1[3] = {(double)p[1].x - p0[0], (double)p[1].y - p0[1], (double)p[1].z - p0[2]};
+    double e2[3] = {(double)p[2].x - p0[0], (double)p[2].y - p0[1], (double)p[2].z - p0[2]};
+    double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    double nu[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
+    double nv[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
+    out[0] = make_float4((float)n[0], (float)n[1], (float)n[2], (float)(n[0] * p0[0] + n[1] * p0[1] + n[2] * p0[2]));
+    out[1] = make_float4((float)nu[0], (float)nu[1], (float)nu[2], (float)-(nu[0] * p0[0] + nu[1] * p0[1] + nu[2] * p0[2]));
+    out[2] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], (float)-(nv[0] * p0[0] + nv[1] * p0[1] + nv[2] * p0[2]));
+}
+
+// Builds the acceleration structure over world-space triangles (pos: ntris x 3 corners).
+// order[slot] = input triangle; nodes = BVH4 nodes (empty for the brute-force accel or a single leaf).
+static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh, std::vector<int> &order,
+                       std::vector<float4> &nodes, uint32_t &bvh_nodes, uint32_t &bvh_depth, uint32_t &stack_entries) {
+    order.resize(ntris);
+    for (uint32_t t = 0; t < ntris; t++) order[t] = (int)t;
+    nodes.clear(); bvh_nodes = 0; bvh_depth = 0; stack_entries = 8;
+    if (!use_bvh) return ZDR_OK;
+    float slo[3] = {3e38f, 3e38f, 3e38f}, shi[3] = {-3e38f, -3e38f, -3e38f};
+    BvhBuilder bb;
+    bb.prims.resize(ntris);
+    for (uint32_t t = 0; t < ntris; t++) {
+        Prim &p = bb.prims[t]; p.tri = (int)t;
+        for (int k = 0; k < 3; k++) {
+            float a = (&pos[3 * (size_t)t].x)[k], b = (&pos[3 * (size_t)t + 1].x)[k], c = (&pos[3 * (size_t)t + 2].x)[k];
+            p.lo[k] = std::min(a, std::min(b, c)); p.hi[k] = std::max(a, std::max(b, c));
+            p.c[k] = 0.5f * (p.lo[k] + p.hi[k]);
+        }
+        BvhBuilder::grow(slo, shi, p.lo, p.hi);
+    }
+    bb.nodes.reserve((size_t)ntris + 16);
+    bb.build(0, (int)ntris, 0);
+    for (uint32_t t = 0; t < ntris; t++) order[t] = bb.prims[t].tri;
+    // conservative padding so that box culling never rejects what the triangle test accepts
+    float diag = sqrtf((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
+    float pad = 4e-6f * diag + 1e-30f;
+    // Collapse to a 4-wide BVH: a node adopts its grandchildren (largest box first) until it has
+    // four children or only leaves.  One node = one 128-byte line, SoA child boxes:
+    //   {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]} {child[4]} {count[4]}
+    // count == 0: child is a node index; count > 0: child is the first slot of a leaf; an unused
+    // child has an inverted box (never hit).  Node 0 is the root; a scene that is one leaf has no nodes.
+    int ninner = 0, worst_stack = 0;
+    if (bb.nodes[0].count == 0) {
+        struct Item { int bnode, id4, stack; };
+        std::vector<Item> todo; todo.push_back({0, 0, 0});
+        ninner = 1;
+        nodes.assign(8, make_float4(0, 0, 0, 0));
+        while (!todo.empty()) {
+            Item it = todo.back(); todo.pop_back();
+            int kids[4], nk = 2;
+            kids[0] = bb.nodes[it.bnode].left; kids[1] = bb.nodes[it.bnode].right;
+            while (nk < 4) {
+                int best = -1; float barea = -1.0f;
+                for (int k = 0; k < nk; k++) {
+                    const BNode &n = bb.nodes[kids[k]];
+                    if (n.count == 0) { float ar = BvhBuilder::area(n.lo, n.hi); if (ar > barea) { barea = ar; best = k; } }
+                }
+                if (best < 0) break;
+                int b = kids[best];
+                kids[best] = bb.nodes[b].left; kids[nk++] = bb.nodes[b].right;
+            }
+            float lo[3][4], hi[3][4]; int child[4], cnt[4];
+            for (int k = 0; k < 4; k++) {
+                if (k < nk) {
+                    const BNode &n = bb.nodes[kids[k]];
+                    for (int ax = 0; ax < 3; ax++) { lo[ax][k] = n.lo[ax] - pad; hi[ax][k] = n.hi[ax] + pad; }
+                    if (n.count) { child[k] = n.first; cnt[k] = n.count; }
+                    else {
+                        child[k] = ninner++; cnt[k] = 0;
+                        nodes.resize(8 * (size_t)ninner, make_float4(0, 0, 0, 0));
+                        todo.push_back({kids[k], child[k], it.stack + nk - 1});
+                    }
+                } else {
+                    for (int ax = 0; ax < 3; ax++) { lo[ax][k] = 3e38f; hi[ax][k] = 3e38f; }
+                    child[k] = 0; cnt[k] = -1;     // unused slot: the traversal skips cnt < 0
+                }
+            }
+            worst_stack = std::max(worst_stack, it.stack + nk - 1);
+            float4 *o = &nodes[8 * (size_t)it.id4];
+            for (int ax = 0; ax < 3; ax++) {
+                o[ax] = make_float4(lo[ax][0], lo[ax][1], lo[ax][2], lo[ax][3]);
+                o[3 + ax] = make_float4(hi[ax][0], hi[ax][1], hi[ax][2], hi[ax][3]);
+            }
+            float f[8]; memcpy(f, child, 16); memcpy(f + 4, cnt, 16);
+            o[6] = make_float4(f[0], f[1], f[2], f[3]); o[7] = make_float4(f[4], f[5], f[6], f[7]);
+        }
+    }
+    if (worst_stack + 5 > ZDR_BVH_STACK) { return fail(ZDR_E_UNSUPPORTED, "BVH needs a deeper traversal stack than ZDR_BVH_STACK"); }   // + 4 slots of slack for the unconditional stores
+    {   // structural self-check before anything reaches the GPU: the nodes form a tree rooted at 0,
+        // every node is referenced once, the leaves tile [0, ntris) exactly, counts fit the 3-bit field
+        std::vector<uint8_t> seen_node(ninner, 0), seen_tri(ntris, 0);
+        bool ok = true;
+        if (ninner) seen_node[0] = 1;
+        for (int i = 0; i < ninner && ok; i++) {
+            int ch[4], ct[4]; memcpy(ch, &nodes[8 * (size_t)i + 6], 16); memcpy(ct, &nodes[8 * (size_t)i + 7], 16);
+            for (int k = 0; k < 4 && ok; k++) {
+                if (ct[k] < 0) continue;
+                if (ct[k] == 0) { ok = ch[k] > i && ch[k] < ninner && !seen_node[ch[k]]; if (ok) seen_node[ch[k]] = 1; }
+                else {
+                    ok = ct[k] <= 7 && ch[k] >= 0 && (uint32_t)(ch[k] + ct[k]) <= ntris;
+                    for (int q = 0; q < ct[k] && ok; q++) { ok = !seen_tri[ch[k] + q]; seen_tri[ch[k] + q] = 1; }
+                }
+            }
+        }
+        for (int i = 0; i < ninner && ok; i++) ok = seen_node[i] != 0;
+        if (ninner) for (uint32_t t = 0; t < ntris && ok; t++) ok = seen_tri[t] != 0;
+        if (!ok) { return fail(ZDR_E_INVALID, "internal error: BVH failed its structural self-check"); }
+    }
+    bvh_nodes = (uint32_t)ninner; bvh_depth = (uint32_t)bb.max_depth;
+    stack_entries = (uint32_t)((worst_stack + 5 + 3) & ~3);   // deepest pending set + the four unconditionally stored slots
+    return ZDR_OK;
+}
+
 // ----------------------------------------------------------------------------------- scene
 struct zdr_scene {
     int device = 0;
     int accel_is_bvh = 0;
     uint32_t ntris = 0, nverts = 0, ninst = 0;
-    uint32_t bvh_nodes = 0, bvh_depth = 0;
+    uint32_t bvh_nodes = 0, bvh_depth = 0, stack_entries = 8;
     std::vector<int32_t> inst_tri_begin;
     std::vector<float> emission;
     float4 *d_isect = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
@@ -196,46 +313,14 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     }
 
     // acceleration structure: slot order + nodes
-    std::vector<int> order(ntris);
-    for (uint32_t t = 0; t < ntris; t++) order[t] = (int)t;
+    std::vector<int> order;
     std::vector<float4> nodes;
     bool use_bvh = (accel == ZDR_ACCEL_BVH) || (accel == ZDR_ACCEL_AUTO && ntris > 64);
-    if (use_bvh) {
-        BvhBuilder bb;
-        bb.prims.resize(ntris);
-        for (uint32_t t = 0; t < ntris; t++) {
-            Prim &p = bb.prims[t]; p.tri = (int)t;
-            for (int k = 0; k < 3; k++) {
-                float a = (&rec[t].p[0].x)[k], b = (&rec[t].p[1].x)[k], c = (&rec[t].p[2].x)[k];
-                p.lo[k] = std::min(a, std::min(b, c)); p.hi[k] = std::max(a, std::max(b, c));
-                p.c[k] = 0.5f * (p.lo[k] + p.hi[k]);
-            }
-        }
-        bb.nodes.reserve(2 * (size_t)ntris / 2 + 16);
-        bb.build(0, (int)ntris, 0);
-        for (uint32_t t = 0; t < ntris; t++) order[t] = bb.prims[t].tri;
-        // conservative padding so that box culling never rejects what the triangle test accepts
-        float diag = sqrtf((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
-        float pad = 4e-6f * diag + 1e-30f;
-        // flatten: inner nodes get consecutive ids in DFS order; the root is id 0 (a lone leaf -> no nodes)
-        std::vector<int> inner_id(bb.nodes.size(), -1);
-        int ninner = 0;
-        for (size_t i = 0; i < bb.nodes.size(); i++) if (bb.nodes[i].count == 0) inner_id[i] = ninner++;
-        nodes.assign(4 * (size_t)ninner, make_float4(0, 0, 0, 0));
-        for (size_t i = 0; i < bb.nodes.size(); i++) {
-            const BNode &n = bb.nodes[i];
-            if (n.count != 0) continue;
-            const BNode &a = bb.nodes[n.left], &b = bb.nodes[n.right];
-            float4 *o = &nodes[4 * (size_t)inner_id[i]];
-            o[0] = make_float4(a.lo[0] - pad, a.lo[1] - pad, a.lo[2] - pad, a.hi[0] + pad);
-            o[1] = make_float4(a.hi[1] + pad, a.hi[2] + pad, b.lo[0] - pad, b.lo[1] - pad);
-            o[2] = make_float4(b.lo[2] - pad, b.hi[0] + pad, b.hi[1] + pad, b.hi[2] + pad);
-            int c0 = a.count ? a.first : inner_id[n.left], c1 = b.count ? b.first : inner_id[n.right];
-            int k0 = a.count, k1 = b.count;
-            float f0, f1, f2, f3; memcpy(&f0, &c0, 4); memcpy(&f1, &c1, 4); memcpy(&f2, &k0, 4); memcpy(&f3, &k1, 4);
-            o[3] = make_float4(f0, f1, f2, f3);
-        }
-        s->bvh_nodes = (uint32_t)ninner; s->bvh_depth = (uint32_t)bb.max_depth;
+    {
+        std::vector<h3> pos(3 * (size_t)ntris);
+        for (uint32_t t = 0; t < ntris; t++) for (int k = 0; k < 3; k++) pos[3 * (size_t)t + k] = rec[t].p[k];
+        int rc = build_accel(pos, ntris, use_bvh, order, nodes, s->bvh_nodes, s->bvh_depth, s->stack_entries);
+        if (rc) { delete s; return rc; }
     }
     s->accel_is_bvh = use_bvh ? 1 : 0;
 
@@ -244,18 +329,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     for (uint32_t slot = 0; slot < ntris; slot++) {
         const TriRec &r = rec[order[slot]];
         slot_of_tri[order[slot]] = (int32_t)slot;
-        {   // plane-form intersection record, float64 -> float32 (accel.h, tri_test)
-            double p0[3] = {r.p[0].x, r.p[0].y, r.p[0].z};
-            double e1[3] = {(double)r.p[1].x - p0[0], (double)r.p[1].y - p0[1], (double)r.p[1].z - p0[2]};
-            double e2[3] = {(double)r.p[2].x - p0[0], (double)r.p[2].y - p0[1], (double)r.p[2].z - p0[2]};
-            double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-            double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-            double nu[3] = {(e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn};
-            double nv[3] = {(n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn};
-            isect[3 * (size_t)slot + 0] = make_float4((float)n[0], (float)n[1], (float)n[2], (float)(n[0] * p0[0] + n[1] * p0[1] + n[2] * p0[2]));
-            isect[3 * (size_t)slot + 1] = make_float4((float)nu[0], (float)nu[1], (float)nu[2], (float)-(nu[0] * p0[0] + nu[1] * p0[1] + nu[2] * p0[2]));
-            isect[3 * (size_t)slot + 2] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], (float)-(nv[0] * p0[0] + nv[1] * p0[1] + nv[2] * p0[2]));
-        }
+        plane_record(r.p, &isect[3 * (size_t)slot]);
         float4 *q = &shade[8 * (size_t)slot];
         q[0] = make_float4(r.p[0].x, r.p[0].y, r.p[0].z, r.uv[0][0]);
         q[1] = make_float4(r.p[1].x, r.p[1].y, r.p[1].z, r.uv[0][1]);
@@ -283,8 +357,30 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     if (e != hipSuccess) { std::string m = hipGetErrorString(e); zdr_scene_destroy(s); return fail(ZDR_E_HIP, "scene upload: " + m); }
     s->ds.isect = s->d_isect; s->ds.shade = s->d_shade; s->ds.nodes = s->d_nodes; s->ds.emission = s->d_emission;
     s->ds.light_insts = s->d_light_insts; s->ds.inst_tri_begin = s->d_inst_tri_begin; s->ds.slot_of_tri = s->d_slot_of_tri;
-    s->ds.ntris = (int32_t)ntris; s->ds.ninst = (int32_t)ninst; s->ds.light_count = light_count; s->ds.nnodes = (int32_t)s->bvh_nodes;
+    s->ds.ntris = (int32_t)ntris; s->ds.ninst = (int32_t)ninst; s->ds.light_count = light_count; s->ds.nnodes = (int32_t)s->bvh_nodes; s->ds.stack_entries = (int32_t)s->stack_entries;
     *out = s;
+    return ZDR_OK;
+}
+
+// Host-only view of the acceleration structure (no GPU needed): lets the CPU test-suite run an
+// emulation of the device traversal on exactly the data the kernels would see.
+extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int accel, float *nodes_out, uint32_t nodes_cap,
+                                     uint32_t *nnodes, uint32_t *stack_entries, int32_t *order_out, float *isect_out) {
+    if (!tri_xyz || !ntris || !nnodes || !order_out || !isect_out) return fail(ZDR_E_INVALID, "null argument");
+    std::vector<h3> pos(3 * (size_t)ntris);
+    for (size_t i = 0; i < 3 * (size_t)ntris; i++) pos[i] = H3(tri_xyz[3 * i], tri_xyz[3 * i + 1], tri_xyz[3 * i + 2]);
+    std::vector<int> order; std::vector<float4> nodes; uint32_t nn = 0, depth = 0, se = 8;
+    bool use_bvh = (accel == ZDR_ACCEL_BVH) || (accel == ZDR_ACCEL_AUTO && ntris > 64);
+    int rc = build_accel(pos, ntris, use_bvh, order, nodes, nn, depth, se); if (rc) return rc;
+    *nnodes = nn;
+    if (stack_entries) *stack_entries = se;
+    if (nn > nodes_cap) return fail(ZDR_E_NOMEM, "nodes_out too small");
+    if (nn) memcpy(nodes_out, nodes.data(), (size_t)nn * 8 * sizeof(float4));
+    for (uint32_t slot = 0; slot < ntris; slot++) {
+        order_out[slot] = order[slot];
+        float4 q[3]; plane_record(&pos[3 * (size_t)order[slot]], q);
+        memcpy(isect_out + 12 * (size_t)slot, q, sizeof q);
+    }
     return ZDR_OK;
 }
 
@@ -301,7 +397,7 @@ extern "C" int zdr_scene_info(const zdr_scene *s, zdr_scene_info_t *info) {
     if (!s || !info) return fail(ZDR_E_INVALID, "null argument");
     info->ntris = s->ntris; info->nverts = s->nverts; info->ninst = s->ninst; info->light_count = (uint32_t)s->ds.light_count;
     info->accel = s->accel_is_bvh ? ZDR_ACCEL_BVH : ZDR_ACCEL_BRUTE;
-    info->bvh_nodes = s->bvh_nodes; info->bvh_max_depth = s->bvh_depth; info->device = s->device; info->device_bytes = s->device_bytes;
+    info->bvh_nodes = s->bvh_nodes; info->bvh_max_depth = s->bvh_depth; info->bvh_stack_entries = s->stack_entries; info->device = s->device; info->device_bytes = s->device_bytes;
     return ZDR_OK;
 }
 

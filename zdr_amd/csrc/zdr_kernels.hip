@@ -72,7 +72,7 @@ ZD void flush_counters(const KernelIO &io, const Counters &cnt) {
 // Forward (and the counting variant): flat regeneration loop, one bounce per trip per live lane.
 template <int SK, class A, bool STATS>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
-    __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     Counters cnt;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
 #endif
 template <int SK, class A>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
-    __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
     __shared__ float4 lds_rec[ZDR_LDS_VERTICES * 4 * WAVE];
     const int lane = threadIdx.x;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path_bwd(DScene S, Rend
 // ---------------------------------------------------------------------- direct / collocated
 template <int INTEG, int SK, class A, bool BWD, bool STATS>
 __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
-    __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     __shared__ float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 1];
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
@@ -253,22 +253,22 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 
 // ----------------------------------------------------------------------------------- launch
 template <int SK, class A>
-static void launch_path(dim3 grid, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
-    if (backward) hipLaunchKernelGGL((k_path_bwd<SK, A>), grid, dim3(WAVE), 0, st, S, R, C, io);
-    else if (stats) hipLaunchKernelGGL((k_path<SK, A, true>), grid, dim3(WAVE), 0, st, S, R, C, io);
-    else hipLaunchKernelGGL((k_path<SK, A, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
+static void launch_path(dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
+    if (backward) hipLaunchKernelGGL((k_path_bwd<SK, A>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    else if (stats) hipLaunchKernelGGL((k_path<SK, A, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    else hipLaunchKernelGGL((k_path<SK, A, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
 }
 template <int INTEG, int SK, class A>
-static void launch_simple(dim3 grid, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
-    if (backward) hipLaunchKernelGGL((k_simple<INTEG, SK, A, true, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
-    else if (stats) hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, true>), grid, dim3(WAVE), 0, st, S, R, C, io);
-    else hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, false>), grid, dim3(WAVE), 0, st, S, R, C, io);
+static void launch_simple(dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
+    if (backward) hipLaunchKernelGGL((k_simple<INTEG, SK, A, true, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    else if (stats) hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    else hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
 }
 template <int SK, class A>
-static void launch_integ(int integrator, dim3 grid, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
-    if (integrator == ZDR_PATH) launch_path<SK, A>(grid, st, S, R, C, io, backward, stats);
-    else if (integrator == ZDR_DIRECT) launch_simple<ZDR_DIRECT, SK, A>(grid, st, S, R, C, io, backward, stats);
-    else launch_simple<ZDR_COLLOCATED, SK, A>(grid, st, S, R, C, io, backward, stats);
+static void launch_integ(int integrator, dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
+    if (integrator == ZDR_PATH) launch_path<SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
+    else if (integrator == ZDR_DIRECT) launch_simple<ZDR_DIRECT, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
+    else launch_simple<ZDR_COLLOCATED, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
 }
 
 int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
@@ -276,12 +276,13 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
     if (nblocks <= 0) return 0;
     dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
+    const size_t dyn = accel_is_bvh ? (size_t)S.stack_entries * WAVE * sizeof(int) : 0;
     if (C.kind == ZDR_SAMPLER_CMJ) {
-        if (accel_is_bvh) launch_integ<0, BvhAccel>(integrator, grid, st, S, R, C, io, backward, stats);
-        else launch_integ<0, BruteAccel>(integrator, grid, st, S, R, C, io, backward, stats);
+        if (accel_is_bvh) launch_integ<0, BvhAccel>(integrator, grid, dyn, st, S, R, C, io, backward, stats);
+        else launch_integ<0, BruteAccel>(integrator, grid, dyn, st, S, R, C, io, backward, stats);
     } else {
-        if (accel_is_bvh) launch_integ<1, BvhAccel>(integrator, grid, st, S, R, C, io, backward, stats);
-        else launch_integ<1, BruteAccel>(integrator, grid, st, S, R, C, io, backward, stats);
+        if (accel_is_bvh) launch_integ<1, BvhAccel>(integrator, grid, dyn, st, S, R, C, io, backward, stats);
+        else launch_integ<1, BruteAccel>(integrator, grid, dyn, st, S, R, C, io, backward, stats);
     }
     if (backward) {   // fold the staging cells into d_material (+=)
         dim3 g((R.tex_w + 63) / 64, R.tex_h);
@@ -297,7 +298,7 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
 // ------------------------------------------------------------------------- ray batch queries
 template <class A, bool ANY>
 __global__ __launch_bounds__(WAVE) void k_trace(DScene S, const float4 *rays, uint32_t n, int32_t *out_i, float *out_f) {
-    __shared__ int lds[A::kNeedsLds ? ZDR_BVH_STACK * WAVE : 1];
+    extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     bool valid = i < n;
     float4 a = valid ? rays[2 * (size_t)i] : make_float4(0, 0, 0, 0), b = valid ? rays[2 * (size_t)i + 1] : make_float4(0, 0, 1, 0);
@@ -320,8 +321,9 @@ int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *ra
     dim3 grid((n + WAVE - 1) / WAVE);
     const float4 *r = (const float4 *)rays;
     if (accel_is_bvh) {
-        if (any) hipLaunchKernelGGL((k_trace<BvhAccel, true>), grid, dim3(WAVE), 0, st, S, r, n, out_i, out_f);
-        else hipLaunchKernelGGL((k_trace<BvhAccel, false>), grid, dim3(WAVE), 0, st, S, r, n, out_i, out_f);
+        const size_t dyn = (size_t)S.stack_entries * WAVE * sizeof(int);
+        if (any) hipLaunchKernelGGL((k_trace<BvhAccel, true>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
+        else hipLaunchKernelGGL((k_trace<BvhAccel, false>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
     } else {
         if (any) hipLaunchKernelGGL((k_trace<BruteAccel, true>), grid, dim3(WAVE), 0, st, S, r, n, out_i, out_f);
         else hipLaunchKernelGGL((k_trace<BruteAccel, false>), grid, dim3(WAVE), 0, st, S, r, n, out_i, out_f);

@@ -160,3 +160,29 @@ def test_update_lights(mat_a):
     scene.update_lights([None, 20.0])
     again = scene.render(m, res=(32, 32), spp=4)
     assert lit[..., :3].max() > 1 and dark[..., :3].max() == 0 and torch.equal(lit, again)
+
+
+def test_instance_transforms(mat_b):
+    """per-instance 4x4 transforms (render.py:83-84,109; interaction.py:19-28).  The native
+    side flattens instances to world space at build time, the oracle transforms at interaction time."""
+    import math
+    from conftest import cbox_models
+    from zdr_amd import float4x4, geometry
+    c, s = math.cos(0.15), math.sin(0.15)
+    room = float4x4.from_rows([[1.0, 0, 0, 0.1], [0, 0.9, 0, 0.2], [0, 0, 1.1, -0.3], [0, 0, 0, 1]])          # non-uniform scale: exercises the inverse-transpose
+    light = float4x4.from_rows([[c, 0, -s, 0.0], [0, 1, 0, -0.6], [s, 0, c, -0.2], [0, 0, 0, 1]])
+    models = [(cbox_models()[0][0], room, 0.0), (cbox_models()[1][0], light, 25.0)]
+    A = geometry.assemble(models)
+    S = oracle.OracleScene.from_arrays(A); Sf = oracle.OracleScene.from_arrays(A, variant="fma")
+    scene = make_scene("path", models=models)
+    W, spp = 64, 16
+    m = torch.from_numpy(mat_b).cuda().requires_grad_()
+    img = scene.render(m, res=(W, W), spp=spp, seed=3)
+    p = oracle_params(scene, W, W, spp, 3, mat_b.shape[:2])
+    ref = S.render_forward(p, mat_b)
+    assert ref[..., :3].mean() > 0.02
+    assert_image_parity(img.detach().cpu().numpy()[..., :3], ref[..., :3], "transformed instances forward", floor=Sf.render_forward(p, mat_b)[..., :3], n_paths=W * W * spp)
+    img.sum().backward()
+    pb = oracle_params(scene, W, W, spp, 4, mat_b.shape[:2])
+    ones = np.ones((W, W, 4), np.float32)
+    assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, ones, mat_b), "transformed instances backward", floor=Sf.render_backward(pb, ones, mat_b), n_paths=W * W * spp)

@@ -102,9 +102,13 @@ def test_million_triangle_tessellated_cbox():
     d = rng.standard_normal((n, 3)); rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); rays[:, 7] = 1e30
     r = torch.from_numpy(rays).cuda()
     ip, bt = scene.trace_closest(r)
-    # the room is closed except for the open front (+z): interior rays heading away from it always hit
+    # the room is closed except for the open front (+z) and the hairline gaps of the original mesh (its
+    # walls do not meet exactly): interior rays heading away from the opening hit as often as they do in
+    # the 32-triangle room, i.e. tessellation + BVH open no new holes
     inward = torch.from_numpy(rays[:, 6] < -0.2).cuda()
-    assert (ip[inward, 0] >= 0).float().mean().item() > 0.9999
+    ip32, _ = make_scene("path").trace_closest(r)
+    hit_big, hit_small = (ip[inward, 0] >= 0).float().mean().item(), (ip32[inward, 0] >= 0).float().mean().item()
+    assert hit_big > 0.999 and abs(hit_big - hit_small) < 3e-4, (hit_big, hit_small)
     tmax = torch.from_numpy(rng.uniform(0.05, 6.0, n).astype(np.float32)).cuda()
     r2 = r.clone(); r2[:, 7] = tmax
     occ = scene.trace_any(r2)

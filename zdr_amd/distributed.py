@@ -119,6 +119,10 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a single-GPU box: ZDR_DIST_BACKEND=gloo ZDR_SHARE_DEVICE=1 puts every rank on cuda:0
+    backend = backend or os.environ.get("ZDR_DIST_BACKEND")
+    if os.environ.get("ZDR_SHARE_DEVICE") == "1":
+        local = 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

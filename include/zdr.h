@@ -24,8 +24,9 @@ extern "C" {
 
 enum { ZDR_OK = 0, ZDR_E_INVALID = -1, ZDR_E_HIP = -2, ZDR_E_UNSUPPORTED = -3, ZDR_E_NOMEM = -4 };
 
-/* integrators = render.py:65-69 */
-enum { ZDR_COLLOCATED = 0, ZDR_DIRECT = 1, ZDR_PATH = 2 };
+/* integrators = render.py:65-69; ZDR_UVGRAD = render_duvdxy's kernel (uvgrad.py:76-98, forward only:
+ * the image receives (dudx, dvdx, dudy, dvdy) per pixel) */
+enum { ZDR_COLLOCATED = 0, ZDR_DIRECT = 1, ZDR_PATH = 2, ZDR_UVGRAD = 3 };
 /* samplers = integrator.py:16-17 (corrmj.py is self-contained; pmj02bn.py needs tables) */
 enum { ZDR_SAMPLER_CMJ = 0, ZDR_SAMPLER_PMJ02BN = 1 };
 /* acceleration structure used for LuisaCompute's Accel (render.py:74,109,127) */

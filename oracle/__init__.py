@@ -15,10 +15,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
-COLLOCATED, DIRECT, PATH = 0, 1, 2
+COLLOCATED, DIRECT, PATH, UVGRAD = 0, 1, 2, 3
 SAMPLER_CMJ, SAMPLER_PMJ02BN = 0, 1
 PRB_CORRECT, PRB_LITERAL = 0, 1
-INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH}
+INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH, "uvgrad": UVGRAD}
 COUNTER_NAMES = ("samples", "closest_rays", "closest_hits", "shadow_rays", "shaded_vertices",
                  "emitter_hits_bsdf", "nan_samples", "grad_scatters")
 

@@ -715,6 +715,42 @@ static void collocated_backward(const zdro_scene *s, const zdro_params *P, const
     if (!v4_any_nan(g)) { write_bsdf_grad(dmat, P->tex_h, P->tex_w, it.uv, g); C->c[C_SCATTER]++; }
 }
 
+/* ------------------------------------------------------------------ uvgrad */
+/* uvgrad.py:6-49 (screen -> texture Jacobian of the primary hit): returns (dudx, dvdx, dudy, dvdy).
+ * Positions are taken in WORLD space (the reference reads the untransformed vertex positions,
+ * uvgrad.py:29-31, which only agrees with its world-space rays for identity transforms). */
+static v4 uvgrad_estimator(const zdro_scene *s, ray_t ray, ray_t rdx, ray_t rdy) {
+    v4 zero = {0, 0, 0, 0};
+    hit_t hit = trace_closest(s, &ray);
+    if (hit.inst < 0) return zero;
+    int t = s->tri_begin[hit.inst] + hit.prim;
+    const float *a = s->verts + 8 * (size_t)s->tris[3 * (size_t)t];
+    const float *b = s->verts + 8 * (size_t)s->tris[3 * (size_t)t + 1];
+    const float *c = s->verts + 8 * (size_t)s->tris[3 * (size_t)t + 2];
+    v3 p0 = s->wp[3 * (size_t)t], p1 = s->wp[3 * (size_t)t + 1], p2 = s->wp[3 * (size_t)t + 2];
+    float w0 = 1.0f - hit.u - hit.v;
+    v3 p = vadd(vadd(vscale(p0, w0), vscale(p1, hit.u)), vscale(p2, hit.v));
+    /* compute_dpduv (uvgrad.py:6-16): dpde = [e1 e2], duvde = [pt1-pt0, pt2-pt0] (columns) */
+    v3 e1 = vsub(p1, p0), e2 = vsub(p2, p0);
+    float m00 = b[3] - a[3], m10 = b[4] - a[4], m01 = c[3] - a[3], m11 = c[4] - a[4]; /* m[row][col] */
+    float det = m00 * m11 - m01 * m10;
+    float i00 = m11 / det, i01 = -m01 / det, i10 = -m10 / det, i11 = m00 / det;       /* inverse */
+    v3 dpdu = vadd(vscale(e1, i00), vscale(e2, i10));
+    v3 dpdv = vneg(vadd(vscale(e1, i01), vscale(e2, i11)));                           /* inverted v */
+    v3 ng = vnormalize(vcross(e1, e2));
+    float t_dx = vdot(vsub(p, rdx.o), ng) / vdot(rdx.d, ng);
+    float t_dy = vdot(vsub(p, rdy.o), ng) / vdot(rdy.d, ng);
+    v3 dpdx = vsub(vadd(rdx.o, vscale(rdx.d, t_dx)), p);
+    v3 dpdy = vsub(vadd(rdy.o, vscale(rdy.d, t_dy)), p);
+    /* (A^T A)^-1 A^T with A = [dpdu dpdv] (uvgrad.py:45-48) */
+    float a00 = vdot(dpdu, dpdu), a01 = vdot(dpdu, dpdv), a11 = vdot(dpdv, dpdv);
+    float d2 = a00 * a11 - a01 * a01;
+    float j00 = a11 / d2, j01 = -a01 / d2, j11 = a00 / d2;
+    float bx0 = vdot(dpdu, dpdx), bx1 = vdot(dpdv, dpdx), by0 = vdot(dpdu, dpdy), by1 = vdot(dpdv, dpdy);
+    v4 r = {j00 * bx0 + j01 * bx1, j01 * bx0 + j11 * bx1, j00 * by0 + j01 * by1, j01 * by0 + j11 * by1};
+    return r;
+}
+
 /* ------------------------------------------------------------------ direct */
 /* Walks direct.py:21-85; when dmat != NULL also accumulates the adjoint of
  * direct.py:89-167 (gradient written at the PRIMARY uv, App. B-11). */
@@ -913,12 +949,19 @@ static ray_t pixel_ray(const zdro_params *P, int x, int y, sampler_t *smp) { /* 
     return generate_ray(P, px, py);
 }
 
+static ray_t pixel_ray_at(const zdro_params *P, float fx, float fy) {
+    float px = 2.0f / (float)P->width * fx - 1.0f;
+    float py = 2.0f / (float)P->height * fy - 1.0f;
+    py *= (float)P->height / (float)P->width;
+    return generate_ray(P, px, py);
+}
+
 static int check_params(const zdro_params *P) {
     if (P->width <= 0 || P->height <= 0 || P->spp == 0) return -1;
     if (P->x0 < 0 || P->y0 < 0 || P->x1 > P->width || P->y1 > P->height) return -1;
     if (P->sample_end > P->spp || P->sample_begin > P->sample_end) return -1;
     if (P->sampler == ZDRO_SAMPLER_PMJ02BN && (!g_pmj || !g_bn)) return -2;
-    if (P->integrator < 0 || P->integrator > 2) return -3;
+    if (P->integrator < 0 || P->integrator > 3) return -3;
     return 0;
 }
 
@@ -938,6 +981,20 @@ int zdro_render_forward(const zdro_scene *s, const zdro_params *P, const float *
         for (int y = P->y0; y < P->y1; y++)
             for (int x = P->x0; x < P->x1; x++) { /* integrator.py:10-29 */
                 v3 sum = V3(0, 0, 0);
+                if (P->integrator == ZDRO_UVGRAD) { /* uvgrad.py:76-98 (scene sampler instead of LC's RNG) */
+                    float s4[4] = {0, 0, 0, 0};
+                    for (uint32_t it = P->sample_begin; it < P->sample_end; it++) {
+                        sampler_t smp = make_sampler(P->sampler, x, y, P->seed, P->spp, it);
+                        v2 off = sampler_next2(&smp);
+                        if (P->use_tent) { off.x = tent_warp1(off.x, 1.0f) + 0.5f; off.y = tent_warp1(off.y, 1.0f) + 0.5f; }
+                        float fx = (float)x + off.x, fy = (float)y + off.y;
+                        v4 g = uvgrad_estimator(s, pixel_ray_at(P, fx, fy), pixel_ray_at(P, fx + 1.0f, fy), pixel_ray_at(P, fx, fy + 1.0f));
+                        if (!v4_any_nan(g)) { s4[0] += g.x; s4[1] += g.y; s4[2] += g.z; s4[3] += g.w; }
+                    }
+                    float *px4 = image + 4 * ((size_t)x + (size_t)y * P->width);
+                    for (int k = 0; k < 4; k++) px4[k] = s4[k] / (float)P->spp;
+                    continue;
+                }
                 for (uint32_t it = P->sample_begin; it < P->sample_end; it++) {
                     sampler_t smp = make_sampler(P->sampler, x, y, P->seed, P->spp, it);
                     ray_t ray = pixel_ray(P, x, y, &smp);

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-enum { ZDRO_COLLOCATED = 0, ZDRO_DIRECT = 1, ZDRO_PATH = 2 };
+enum { ZDRO_COLLOCATED = 0, ZDRO_DIRECT = 1, ZDRO_PATH = 2, ZDRO_UVGRAD = 3 /* render_duvdxy, uvgrad.py */ };
 enum { ZDRO_SAMPLER_CMJ = 0, ZDRO_SAMPLER_PMJ02BN = 1 };
 /* PRB BSDF-sample adjoint form: corrected or the literal
  * weight of prb.py:162 (kept only to document the deviation). */

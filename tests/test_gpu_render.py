@@ -186,3 +186,16 @@ def test_instance_transforms(mat_b):
     pb = oracle_params(scene, W, W, spp, 4, mat_b.shape[:2])
     ones = np.ones((W, W, 4), np.float32)
     assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, ones, mat_b), "transformed instances backward", floor=Sf.render_backward(pb, ones, mat_b), n_paths=W * W * spp)
+
+
+def test_render_duvdxy_matches_oracle(cbox_oracle, mat_a):
+    scene = make_scene("direct")
+    m = torch.from_numpy(mat_a).cuda()
+    got = scene.render_duvdxy(m, res=(128, 128), spp=16, seed=3).cpu().numpy()
+    p = oracle_params(scene, 128, 128, 16, 3, mat_a.shape[:2])
+    p.integrator = oracle.UVGRAD
+    ref = cbox_oracle.render_forward(p, mat_a)
+    assert np.abs(ref).max() > 1e-3
+    d = np.abs(got - ref)
+    # pixels whose primary ray grazes a triangle edge may pick the neighbouring triangle
+    assert (d > 1e-5 + 1e-3 * np.abs(ref)).mean() < 2e-3, (d.max(), (d > 1e-5 + 1e-3 * np.abs(ref)).mean())

@@ -142,3 +142,38 @@ def test_update_lights_switches_emitters(cbox_arrays, cbox_material):
     S.set_emissions(np.zeros((2, 3), np.float32))
     dark = S.render_forward(p, cbox_material)
     assert lit[..., :3].max() > 1 and dark[..., :3].max() == 0
+
+
+def test_uvgrad_matches_float64_ray_differences():
+    """render_duvdxy (uvgrad.py): on a planar quad with an affine uv map the Jacobian equals the uv
+    difference between the hits of the rays through (x+1, y) / (x, y+1) and through (x, y); v is inverted."""
+    A = quad_scene()
+    S = oracle.OracleScene.from_arrays(A)
+    cam = (0.6, (0.3, 2.0, 0.4), (0.0, 0.0, 0.0), (0.0, 0.0, -1.0))
+    W = 12
+    p = oracle.make_params("uvgrad", W, W, 1, 0, cam, (4, 4), use_tent=False)
+    img = S.render_forward(p, np.zeros((4, 4, 4), np.float32))
+    o = np.array(cam[1], np.float64)
+    fwd = np.array(cam[2]) - o; fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, cam[3]); right /= np.linalg.norm(right)
+    upp = np.cross(right, fwd)
+
+    def uv_at(fx, fy):
+        px = (2.0 / W * fx - 1.0) * np.tan(0.3); py = (2.0 / W * fy - 1.0) * np.tan(0.3)
+        d = px * right - py * upp + fwd; d /= np.linalg.norm(d)
+        hit = o + (-o[1] / d[1]) * d
+        return np.array([(hit[0] + 1) / 2, (hit[2] + 1) / 2]), hit     # quad_scene: u = (x+1)/2, v = (z+1)/2
+
+    checked = 0
+    for y in range(W):
+        for x in range(W):
+            off = oracle.sampler_dump(oracle.SAMPLER_CMJ, x, y, 0, 1, 0, nvert=0)
+            fx, fy = x + off[0], y + off[1]
+            uv, hit = uv_at(fx, fy)
+            if abs(hit[0]) > 0.95 or abs(hit[2]) > 0.95:
+                continue
+            ux, _ = uv_at(fx + 1, fy); uy, _ = uv_at(fx, fy + 1)
+            exp = [ux[0] - uv[0], -(ux[1] - uv[1]), uy[0] - uv[0], -(uy[1] - uv[1])]
+            np.testing.assert_allclose(img[y, x], exp, rtol=2e-4, atol=2e-6)
+            checked += 1
+    assert checked > 20

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libzdr_hip.so")
 
-COLLOCATED, DIRECT, PATH = 0, 1, 2
+COLLOCATED, DIRECT, PATH, UVGRAD = 0, 1, 2, 3
 SAMPLER_CMJ, SAMPLER_PMJ02BN = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH}   # render.py:65-69

@@ -61,6 +61,36 @@ ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io,
     return ggx_brdf_from(g, wo, mk3(m.x, m.y, m.z)) * li;
 }
 
+// -------------------------------------------------------------------------------- uvgrad
+// uvgrad.py:6-49: Jacobian of the texture coordinates of the primary hit w.r.t. the pixel position,
+// (dudx, dvdx, dudy, dvdy), from the hits of the rays through (x+1, y) and (x, y+1) with the hit
+// triangle's plane.  World-space positions (see oracle/zdr_oracle.c uvgrad_estimator).
+template <class A>
+ZD float4 uvgrad_sample(const DScene &S, int *lds, f3 o, f3 d, f3 odx, f3 ddx, f3 ody, f3 ddy) {
+    Hit h = A::closest(S, lds, o, d, 0.0f, 1e30f);
+    if (h.slot < 0) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 *r = S.shade + 8 * (size_t)h.slot;
+    float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
+    f3 p0 = xyz(r0), p1 = xyz(r1), p2 = xyz(r2);
+    float w0 = 1.0f - h.u - h.v;
+    f3 p = p0 * w0 + p1 * h.u + p2 * h.v;
+    f3 e1 = p1 - p0, e2 = p2 - p0;
+    float m00 = r2.w - r0.w, m10 = r3.w - r1.w, m01 = r4.w - r0.w, m11 = r5.w - r1.w;   // [pt1-pt0, pt2-pt0] as columns
+    float idet = rcp(m00 * m11 - m01 * m10);
+    float i00 = m11 * idet, i01 = -m01 * idet, i10 = -m10 * idet, i11 = m00 * idet;
+    f3 dpdu = e1 * i00 + e2 * i10;
+    f3 dpdv = -(e1 * i01 + e2 * i11);                                                  // inverted v (uvgrad.py:15)
+    f3 ng = xyz(r6);
+    float t_dx = dot(p - odx, ng) * rcp(dot(ddx, ng));
+    float t_dy = dot(p - ody, ng) * rcp(dot(ddy, ng));
+    f3 dpdx = (odx + ddx * t_dx) - p, dpdy = (ody + ddy * t_dy) - p;
+    float a00 = dot(dpdu, dpdu), a01 = dot(dpdu, dpdv), a11 = dot(dpdv, dpdv);
+    float id2 = rcp(a00 * a11 - a01 * a01);
+    float j00 = a11 * id2, j01 = -a01 * id2, j11 = a00 * id2;
+    float bx0 = dot(dpdu, dpdx), bx1 = dot(dpdv, dpdx), by0 = dot(dpdu, dpdy), by1 = dot(dpdv, dpdy);
+    return make_float4(j00 * bx0 + j01 * bx1, j01 * bx0 + j11 * bx1, j00 * by0 + j01 * by1, j01 * by0 + j11 * by1);
+}
+
 // -------------------------------------------------------------------------------- direct
 // direct.py:21-85 (forward) / 89-167 (adjoint; gradient written once at the primary uv, App. B-11)
 template <int SK, class A, bool BWD, bool STATS>

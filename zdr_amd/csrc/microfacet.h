@@ -71,18 +71,15 @@ ZD float ggx_dfdr_from(const GgxTerms &g, f3 wi, float roughness) {
     return 4.0f * r3 * (g.F * wi.z * g.inv4) * dS;
 }
 
-ZD f3 cosine_sample_hemisphere(f2 u) {                         // microfacet.py:34-37
-    float r = fsqrt(u.x), phi = 2.0f * ZDR_PI * u.y;
-    return mk3(r * cosf(phi), r * sinf(phi), fsqrt(1.0f - u.x));
-}
-
-ZD f3 sample_wm(f3 w, float alpha, f2 u) {                     // microfacet.py:72-92 (pbrt-v4 VNDF)
+// Both lobes of ggx_sample warp the same polar point of the unit disk: r = sqrt(u.x), angle 2 pi u.y
+// (cosine_sample_hemisphere, microfacet.py:34-37, and SampleUniformDiskPolar, :61-65).  In a wavefront
+// the two branches are both executed (the lobe is chosen per lane), so the disk point — one sincos —
+// is computed once, before the branch.
+ZD f3 sample_wm_disk(f3 w, float alpha, float px, float py) {      // microfacet.py:72-92 (pbrt-v4 VNDF)
     f3 wh = normalize(mk3(alpha * w.x, alpha * w.y, w.z));
     if (wh.z < 0.0f) wh = -wh;
     f3 T1 = (wh.z < 0.99999f) ? normalize(cross(mk3(0.0f, 0.0f, 1.0f), wh)) : mk3(1.0f, 0.0f, 0.0f);
     f3 T2 = cross(wh, T1);
-    float r = fsqrt(u.x), theta = 2.0f * ZDR_PI * u.y;           // SampleUniformDiskPolar :61-65
-    float px = r * cosf(theta), py = r * sinf(theta);
     float h = fsqrt(1.0f - px * px);
     py = lerpf(h, py, (1.0f + wh.z) * 0.5f);
     float pz = fsqrt(fmaxf(0.0f, 1.0f - (px * px + py * py)));
@@ -91,8 +88,12 @@ ZD f3 sample_wm(f3 w, float alpha, f2 u) {                     // microfacet.py:
 }
 
 ZD f3 ggx_sample(f3 wo, float roughness, float u_lobe, f2 u2) {  // microfacet.py:41-49
-    if (u_lobe < 0.5f) return cosine_sample_hemisphere(u2);
-    f3 wm = sample_wm(wo, roughness * roughness, u2);
+    float r = fsqrt(u2.x), phi = 2.0f * ZDR_PI * u2.y;
+    float sn, cs;
+    sincosf(phi, &sn, &cs);
+    float px = r * cs, py = r * sn;
+    if (u_lobe < 0.5f) return mk3(px, py, fsqrt(1.0f - u2.x));    // cosine lobe
+    f3 wm = sample_wm_disk(wo, roughness * roughness, px, py);
     f3 i = -wo;                                                 // reflect(-wo, wm)
     return i - wm * (2.0f * dot(wm, i));
 }

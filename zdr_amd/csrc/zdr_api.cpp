@@ -454,7 +454,8 @@ static int make_sampler_cfg(const zdr_scene *s, int32_t sampler, uint32_t seed, 
 }
 
 static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg &R) {
-    if (p->integrator < 0 || p->integrator > 2) return fail(ZDR_E_INVALID, "unknown integrator");
+    if (p->integrator < 0 || p->integrator > ZDR_UVGRAD) return fail(ZDR_E_INVALID, "unknown integrator");
+    if (p->integrator == ZDR_UVGRAD && backward) return fail(ZDR_E_UNSUPPORTED, "render_duvdxy has no backward pass");
     if (p->width <= 0 || p->height <= 0) return fail(ZDR_E_INVALID, "bad resolution");
     if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 > p->x1 || p->y0 > p->y1) return fail(ZDR_E_INVALID, "bad pixel rectangle");
     if (p->sample_begin > p->sample_end || p->sample_end > p->spp) return fail(ZDR_E_INVALID, "bad sample range");
@@ -492,6 +493,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     long want = tiles > 0 ? (target_waves + tiles - 1) / tiles : 1;
     long maxc = std::max<long>(1, ns / min_chunk);
     long nchunks = std::max<long>(1, std::min(want, maxc));
+    if (p->integrator == ZDR_UVGRAD) nchunks = 1;        // four-channel output, written directly
     if (const char *e = getenv("ZDR_DEBUG_NO_SCATTER")) R.debug_no_scatter = atoi(e);
     R.chunk = ns ? (uint32_t)((ns + nchunks - 1) / nchunks) : 1;
     R.nchunks = ns ? (int32_t)((ns + R.chunk - 1) / R.chunk) : 0;
@@ -537,6 +539,7 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (!backward && !stats && !io.image) return fail(ZDR_E_INVALID, "forward needs an image");
     if (!backward && !stats && R.nchunks > 1 && !io.partial) return fail(ZDR_E_NOMEM, "chunk workspace missing");
     if (stats && !io.counters) return fail(ZDR_E_NOMEM, "counter buffer missing");
+    if (stats && p->integrator == ZDR_UVGRAD) return fail(ZDR_E_UNSUPPORTED, "no statistics for render_duvdxy");
     if (zdr_launch_render(s->ds, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
         return fail(ZDR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(hipGetLastError()));
     return ZDR_OK;

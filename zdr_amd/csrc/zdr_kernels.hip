@@ -240,6 +240,35 @@ __global__ void k_cells_to_grad(const float4 *__restrict__ cells, float4 *__rest
     dmat[(size_t)x + (size_t)tex_w * y] = make_float4(d.x + acc.x, d.y + acc.y, d.z + acc.z, d.w + acc.w);
 }
 
+// render_duvdxy (uvgrad.py:76-98): mean over the samples of the screen->texture Jacobian, NaNs dropped
+template <int SK, class A>
+__global__ __launch_bounds__(WAVE) void k_uvgrad(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+    extern __shared__ int lds[];
+    const WorkItem w = decode_block(R);
+    const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
+    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t it = w.s_begin; it < w.s_end; it++) {
+        if (!w.valid) continue;
+        Sampler smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
+        f2 off = sampler_next2<SK>(C, smp);
+        if (R.use_tent) { off.x = tent_warp1(off.x) + 0.5f; off.y = tent_warp1(off.y) + 0.5f; }
+        const float fx = (float)w.x + off.x, fy = (float)w.y + off.y;
+        f3 o = ld3(R.cam_o), d[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {          // rays through (x, y), (x + 1, y), (x, y + 1)
+            float px = R.two_over_w * (fx + (k == 1 ? 1.0f : 0.0f)) - 1.0f;
+            float py = (R.two_over_h * (fy + (k == 2 ? 1.0f : 0.0f)) - 1.0f) * R.aspect;
+            d[k] = normalize((ld3(R.cam_right) * (px * R.cam_tan) - ld3(R.cam_upp) * (py * R.cam_tan)) + ld3(R.cam_fwd));
+        }
+        float4 g = uvgrad_sample<A>(S, lds, o, d[0], o, d[1], o, d[2]);
+        if (!any_nan4(g)) { sum.x += g.x; sum.y += g.y; sum.z += g.z; sum.w += g.w; }
+    }
+    if (w.valid) {
+        float fs = (float)C.spp;
+        io.image[w.pix] = make_float4(__fdiv_rn(sum.x, fs), __fdiv_rn(sum.y, fs), __fdiv_rn(sum.z, fs), __fdiv_rn(sum.w, fs));
+    }
+}
+
 // sums the per-chunk partial images in chunk order (deterministic), integrator.py:29
 __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial, float4 *image) {
     int x = R.x0 + blockIdx.x * blockDim.x + threadIdx.x, y = R.y0 + blockIdx.y;
@@ -266,7 +295,8 @@ static void launch_simple(dim3 grid, size_t dyn, hipStream_t st, const DScene &S
 }
 template <int SK, class A>
 static void launch_integ(int integrator, dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
-    if (integrator == ZDR_PATH) launch_path<SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
+    if (integrator == ZDR_UVGRAD) hipLaunchKernelGGL((k_uvgrad<SK, A>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    else if (integrator == ZDR_PATH) launch_path<SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
     else if (integrator == ZDR_DIRECT) launch_simple<ZDR_DIRECT, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
     else launch_simple<ZDR_COLLOCATED, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
 }

@@ -102,9 +102,9 @@ class Scene:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _params(self, res, spp, seed, tex_hw, rect=None, samples=None, camera=None) -> N.RenderParams:
+    def _params(self, res, spp, seed, tex_hw, rect=None, samples=None, camera=None, integrator=None) -> N.RenderParams:
         p = N.RenderParams()
-        p.integrator, p.sampler = self._integrator, N.SAMPLERS[self.sampler]
+        p.integrator, p.sampler = self._integrator if integrator is None else integrator, N.SAMPLERS[self.sampler]
         p.width, p.height = int(res[0]), int(res[1])
         p.spp, p.seed = int(spp), int(seed) & 0xFFFFFFFF            # seeds are uint32 (App. B-15)
         p.use_tent = int(bool(self.use_tent_filter))
@@ -120,7 +120,7 @@ class Scene:
         if material.device != self.device or material.dtype != torch.float32:
             raise ValueError(f"material must be a float32 tensor on {self.device}")
 
-    def render_forward(self, material, res, spp, seed, *, rect=None, samples=None, out=None):
+    def render_forward(self, material, res, spp, seed, *, rect=None, samples=None, out=None, kernel=None):
         """render.py:159-173.  Returns the (H, W, 4) image; with ``rect``/``samples`` only that shard
         is written (other pixels of ``out`` keep their value; a fresh image is zero-filled)."""
         self._check_material(material)
@@ -130,7 +130,7 @@ class Scene:
             image = (torch.empty if full else torch.zeros)((res[1], res[0], 4), dtype=torch.float32, device=self.device)
         else:
             image = out
-        p = self._params(res, spp, seed, material.shape[0:2], rect, samples)
+        p = self._params(res, spp, seed, material.shape[0:2], rect, samples, integrator=kernel)
         N.check(N.lib().zdr_render_forward(self._handle, C.byref(p), material.data_ptr(), image.data_ptr(), self._stream()))
         return image
 
@@ -181,7 +181,11 @@ class Scene:
         return Scene.RenderOperator.apply(material, self, res, spp, seed)
 
     def render_duvdxy(self, material, *, res, spp, seed=0):
-        raise NotImplementedError("render_duvdxy (uvgrad.py) is outside the hot path built so far (SURVEY §8f-4)")
+        """Gradient of the texture coordinates w.r.t. screen-space coordinates: a (height, width, 4) tensor
+        holding (dudx, dvdx, dudy, dvdy) (render.py:243-257, uvgrad.py).  Not differentiable.  The
+        reference drives this kernel with LuisaCompute's own random sampler (uvgrad.py:82, third-party);
+        here the scene's sampler provides the pixel jitter."""
+        return self.render_forward(material.detach(), res, spp, seed, kernel=N.UVGRAD)
 
     # ------------------------------------------------------------------- test / debug hooks
     def trace_closest(self, rays):

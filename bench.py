@@ -36,6 +36,15 @@ def algorithmic_bytes(stats, spp, backward):
     return a, (H, V, E)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC pass (separate rocprofv3 --pmc runs of
+    the same workload, tools/pmc_passes.sh); None when the workload differs from the profiled one."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[kernel]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene, mat_np, W, spp_sample):
     """The oracle (a scalar C port, OpenMP over pixels) on the host cores, bounded sample of the same workload."""
     import oracle
@@ -139,7 +148,8 @@ def main():
             "path_stats": {"closest_hits_per_sample": round(Hb, 4), "shaded_vertices_per_sample": round(Vb, 4), "emitter_hits_bsdf_per_sample": round(Eb, 5),
                            "closest_rays_per_sample": round(stats["closest_rays"] / stats["samples"], 4)},
             "roofline": {"bound": "hbm", "kernel": "k_path<cmj, brute, backward>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("k_path_bwd") if (W, spp, args.integrator) == (512, 256, "path") else None, "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": round(a_bwd * n_per_pass),
                          "bytes_per_sample": {"fwd": round(a_fwd, 1), "bwd": round(a_bwd, 1)},
                          "fwd_achieved": round(a_fwd * n_per_pass / (fwd_ms * 1e-3) / 1e9, 2)},
         }

@@ -17,7 +17,7 @@ _LIBS = {}
 
 COLLOCATED, DIRECT, PATH, UVGRAD = 0, 1, 2, 3
 SAMPLER_CMJ, SAMPLER_PMJ02BN = 0, 1
-PRB_CORRECT, PRB_LITERAL = 0, 1
+PRB_CORRECT, PRB_LITERAL, PRB_DETACHED = 0, 1, 2
 INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH, "uvgrad": UVGRAD}
 COUNTER_NAMES = ("samples", "closest_rays", "closest_hits", "shadow_rays", "shaded_vertices",
                  "emitter_hits_bsdf", "nan_samples", "grad_scatters")

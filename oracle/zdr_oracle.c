@@ -535,6 +535,23 @@ static v4 ggx_brdf_grad(v3 wo, v3 wi, v3 diffuse, float specular, float roughnes
     return out;
 }
 
+/* d ln(ggx_sample_pdf) / d roughness (microfacet.py:52-58): only the glossy half depends on it,
+ * glossy = G1(wo) D(wm) / (4 |wo.z|). */
+static float ggx_dlnpdf_dr(v3 wo, v3 wi, float roughness) {
+    float alpha = roughness * roughness, a2 = alpha * alpha;
+    v3 wm = vnormalize(vadd(wi, wo));
+    float nh = fmaxf(0.00001f, wm.z), nh2 = nh * nh;
+    float tt = nh2 * (a2 - 1.0f) + 1.0f;
+    float D = a2 / (PI_F * tt * tt);
+    float dD = (1.0f - nh2 * (1.0f + a2)) / (PI_F * tt * tt * tt);
+    float nvo = fmaxf(0.00001f, wo.z);
+    float ko = (1.0f - nvo * nvo) / (nvo * nvo), so = sqrtf(1.0f + a2 * ko);
+    float G1o = 2.0f / (1.0f + so), dG1o = -ko / (so * (1.0f + so) * (1.0f + so));
+    float dglossy = (dG1o * D + G1o * dD) / (4.0f * fabsf(wo.z));
+    float dp = 0.5f * dglossy * 4.0f * roughness * roughness * roughness;
+    return dp / ggx_sample_pdf(wo, wi, roughness);
+}
+
 void zdro_ggx_brdf(const float wo[3], const float wi[3], const float d[3], float r, float out[3]) {
     v3 f = ggx_brdf(V3(wo[0], wo[1], wo[2]), V3(wi[0], wi[1], wi[2]), V3(d[0], d[1], d[2]), 0.04f, r);
     out[0] = f.x; out[1] = f.y; out[2] = f.z;
@@ -820,18 +837,24 @@ static v3 direct_walk(const zdro_scene *s, const zdro_params *P, const float *ma
 }
 
 /* -------------------------------------------------------------------- path */
+static int g_debug_rr_clamp = 0;
+void zdro_debug_rr_clamp(int on) { g_debug_rr_clamp = on; }
 #define ZDRO_MAX_DEPTH 64
 typedef struct {
     v2 uv; v4 mat; v3 wo;
     int has_nee; v3 wi_light, W;   /* W = mis * eval / max(pdf_light, 1e-4) */
     int has_bsdf; v3 wi; float pdf, q; /* bounce continued: f/pdf/q multiplies beta */
     v3 beta;                       /* throughput on entry */
+    int rr_scaled, rr_norm;        /* RR divided beta by q = lum(beta') (>= 0.05); ... and lum(beta') >= 1 */
+    float nee_pb_frac;             /* pdf_bsdf / (pdf_light + pdf_bsdf) of the accepted light sample */
+    v3 beta_out;                   /* throughput leaving the vertex (unit luminance when rr_scaled) */
 } path_vertex_t;
 
 /* prb.py:19-88 with the current helper signatures (App. B-1). Optionally records
  * the shaded vertices (for the adjoint sweep) and the terminal emitter term. */
 static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat, ray_t ray, sampler_t *smp,
-                    path_vertex_t *rec, int *nrec, v3 *terminal_Li, counters_t *C) {
+                    path_vertex_t *rec, int *nrec, v3 *terminal_Li, counters_t *C, float *terminal_pl_frac) {
+    if (terminal_pl_frac) *terminal_pl_frac = 0.0f;
     v3 radiance = V3(0, 0, 0), beta = V3(1, 1, 1);
     float pdf_bsdf = 1e30f;
     int nr = 0;
@@ -851,6 +874,7 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
             v3 em = V3(e[0], e[1], e[2]);
             radiance = vadd(radiance, vmul(vscale(beta, mis), em));
             if (terminal_Li) *terminal_Li = vscale(em, mis);
+            if (terminal_pl_frac) *terminal_pl_frac = (pdf_bsdf + pdf_light > 1e-4f) ? pdf_light / (pdf_bsdf + pdf_light) : 0.0f;
             if (depth > 0) C->c[C_EMIT_BSDF]++;
             break;
         }
@@ -875,7 +899,8 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
             float mis = balanced_heuristic(light.pdf, pb);
             float dn = fmaxf(light.pdf, 1e-4f);
             radiance = vadd(radiance, vdivs(vmul(vscale(vmul(beta, bsdf), mis), light.eval), dn));
-            if (pv) { pv->has_nee = 1; pv->wi_light = wil; pv->W = vdivs(vscale(light.eval, mis), dn); }
+            if (pv) { pv->has_nee = 1; pv->wi_light = wil; pv->W = vdivs(vscale(light.eval, mis), dn);
+                      pv->nee_pb_frac = (light.pdf + pb > 1e-4f) ? pb / (light.pdf + pb) : 0.0f; }
         }
         v3 wi_local = ggx_sample(wo, roughness, smp);
         pdf_bsdf = ggx_sample_pdf(wo, wi_local, roughness);
@@ -888,11 +913,13 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
             float l = 0.212671f * beta.x + 0.715160f * beta.y + 0.072169f * beta.z;
             if (l == 0.0f) break;
             q = fmaxf(l, 0.05f);
+            if (g_debug_rr_clamp) q = fminf(q, 1.0f);   /* diagnostic only (env ZDRO_DEBUG_RR_CLAMP): unbiased RR */
             float r = sampler_next(smp);
             if (r >= q) break;
             beta = vdivs(beta, q);
+            if (pv && l >= 0.05f && !(g_debug_rr_clamp && l >= 1.0f)) { pv->rr_scaled = 1; pv->rr_norm = l >= 1.0f; }
         }
-        if (pv) { pv->has_bsdf = 1; pv->wi = wi_local; pv->pdf = pdf_bsdf; pv->q = q; }
+        if (pv) { pv->has_bsdf = 1; pv->wi = wi_local; pv->pdf = pdf_bsdf; pv->q = q; pv->beta_out = beta; }
     }
     if (nrec) *nrec = nr;
     return radiance;
@@ -904,10 +931,36 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
 static void path_backward(const zdro_scene *s, const zdro_params *P, const float *mat, double *dmat, ray_t ray,
                           sampler_t *smp, v3 le_grad, counters_t *C) {
     path_vertex_t rec[ZDRO_MAX_DEPTH];
-    int n = 0; v3 Li;
-    v3 Le = path_walk(s, P, mat, ray, smp, rec, &n, &Li, C);
+    int n = 0; v3 Li; float term_pl_frac = 0.0f;
+    v3 Le = path_walk(s, P, mat, ray, smp, rec, &n, &Li, C, &term_pl_frac);
     if (vany_nan(Le)) return; /* prb.py:100 */
     const float specular = 0.04f;
+    /* Adjoint sweep, last vertex to first, extended to the derivative of the forward's
+     * EXPECTATION under the reference's Russian roulette.  prb.py:83 does not clamp q = max(lum(beta'), 0.05)
+     * to 1, so there are three kinds of vertex (beta' = beta f / pdf, l = lum(beta')):
+     *   P  no RR (depth < rr_depth) or l < 0.05 (q constant): plain product;
+     *   T  0.05 <= l < 1: survive with probability l, divide by l — unbiased, but the realised throughput
+     *      leaves with unit luminance and the survival probability S picks up the factor l;
+     *   N  l >= 1: survive with certainty and STILL divide by l: the expected throughput becomes
+     *      S * beta'/lum(beta') — renormalised, biased, and a function of the material through the colour
+     *      ratio, through S (earlier T vertices) and through the sampling density at this vertex (the
+     *      factor 1/pdf no longer survives).
+     * With E = expected throughput and S = survival probability: P: E' = E u;  T: E' = E u, S' = lum(E u);
+     * N: E' = S E u / lum(E u).  Reverse mode over that recursion, evaluated on the realised path
+     * (A = dL/dE in units of the realised beta = arriving radiance, s = dL/dS):
+     *   P: Aeff = A;                 s stays
+     *   T: Aeff = A + s w;           s = 0                      (w = luminance weights, prb.py:80)
+     *   N: Aeff = A - w (b . A);     s += b . A;   Z = <g, b L>  (L = plain arriving radiance; b = beta leaving)
+     *   grad += d f[(beta/(pdf q)) Aeff];   A = g fL W + (f/(pdf q)) Aeff
+     *   grad_r += dln(pdf)/dr Z  at EVERY vertex: renormalisation discards all scalar factors gathered since
+     *   the last T vertex (whose S carries them on), so the sampling densities of all those vertices lose
+     *   their 1/pdf compensation: Z is set at N, cleared at T and inherited through P vertices.
+     * The renormalisation mixes the colour channels, so A is the adjoint of the SCALAR <g, L> (g = the
+     * pixel's cotangent), i.e. it is carried already multiplied by g.
+     * ZDRO_PRB_DETACHED keeps every RR factor constant (what the reference's autodiff blocks do). */
+    const v3 wl = V3(0.212671f, 0.715160f, 0.072169f);
+    float sS = 0.0f, Zs = 0.0f;
+    v3 Lg = vmul(Li, le_grad);       /* g-contracted adjoint; Li stays the plain radiance for ZDRO_PRB_LITERAL */
     for (int k = n - 1; k >= 0; k--) {
         path_vertex_t *v = &rec[k];
         v3 diffuse = V3(v->mat.x, v->mat.y, v->mat.z); float r = v->mat.w;
@@ -917,8 +970,14 @@ static void path_backward(const zdro_scene *s, const zdro_params *P, const float
             fL = ggx_brdf(v->wo, v->wi_light, diffuse, specular, r);
             v4 g = ggx_brdf_grad(v->wo, v->wi_light, diffuse, specular, r, vmul(vmul(v->beta, v->W), le_grad));
             grad.x += g.x; grad.y += g.y; grad.z += g.z; grad.w += g.w;
+            if (P->prb_mode == ZDRO_PRB_CORRECT)   /* d w_nee / dr = -w_nee pb/(pl+pb) dln(pb)/dr */
+                grad.w -= vdot(vmul(vmul(v->beta, vmul(fL, v->W)), le_grad), V3(1, 1, 1)) * v->nee_pb_frac * ggx_dlnpdf_dr(v->wo, v->wi_light, r);
         }
-        v3 T = V3(0, 0, 0);
+        if (P->prb_mode == ZDRO_PRB_CORRECT && k == n - 1 && v->has_bsdf)   /* d w_bsdf / dr of the emitter hit that ended the path */
+            grad.w += vdot(v->beta_out, Lg) * term_pl_frac * ggx_dlnpdf_dr(v->wo, v->wi, r);
+        v3 T = V3(0, 0, 0), Y = Lg;
+        float score = 0.0f;
+        if (!v->has_bsdf) { sS = 0.0f; Zs = 0.0f; }   /* the path stops here: nothing downstream */
         if (v->has_bsdf) { /* prb.py:157-163, corrected */
             v3 f = ggx_brdf(v->wo, v->wi, diffuse, specular, r);
             T = vdivs(vdivs(f, v->pdf), v->q);
@@ -927,11 +986,29 @@ static void path_backward(const zdro_scene *s, const zdro_params *P, const float
                 v3 Le_rem = vmul(vmul(v->beta, T), Li);     /* what prb.py keeps in Le after the subtractions */
                 ct = vmul(vmul(vdivs(v->beta, v->pdf), Le_rem), le_grad);
             } else {
-                ct = vmul(vmul(vdivs(vdivs(v->beta, v->pdf), v->q), Li), le_grad);
+                v3 Aeff = Lg;
+                if (P->prb_mode == ZDRO_PRB_CORRECT && v->rr_scaled) {
+                    if (v->rr_norm) {                                   /* N */
+                        float ba = vdot(v->beta_out, Lg);
+                        Aeff = vsub(Lg, vscale(wl, ba));
+                        sS += ba;
+                        /* the score multiplies the downstream VALUE <g, b L>, not b . A: later renormalisations make
+                         * the downstream homogeneous of degree 0 in beta, so b . (gradient) would drop them (Euler) */
+                        Zs = vdot(vmul(le_grad, v->beta_out), Li);
+                    } else {                                            /* T */
+                        Aeff = vadd(Lg, vscale(wl, sS));
+                        sS = 0.0f;
+                        Zs = 0.0f;
+                    }
+                }
+                if (P->prb_mode == ZDRO_PRB_CORRECT && Zs != 0.0f) score = ggx_dlnpdf_dr(v->wo, v->wi, r) * Zs;
+                Y = Aeff;
+                ct = vmul(vdivs(vdivs(v->beta, v->pdf), v->q), Aeff);
             }
             v4 g = ggx_brdf_grad(v->wo, v->wi, diffuse, specular, r, ct);
-            grad.x += g.x; grad.y += g.y; grad.z += g.z; grad.w += g.w;
+            grad.x += g.x; grad.y += g.y; grad.z += g.z; grad.w += g.w + score;
         }
+        Lg = vadd(vmul(vmul(fL, v->W), le_grad), vmul(T, Y));
         Li = vadd(vmul(fL, v->W), vmul(T, Li));
         if (v4_any_nonzero(grad) && !v4_any_nan(grad)) { /* prb.py:178-187 */
             write_bsdf_grad(dmat, P->tex_h, P->tex_w, v->uv, grad); C->c[C_SCATTER]++;
@@ -1002,7 +1079,7 @@ int zdro_render_forward(const zdro_scene *s, const zdro_params *P, const float *
                     C.c[C_SAMPLES]++;
                     if (P->integrator == ZDRO_COLLOCATED) rad = collocated_estimator(s, P, material, ray, &C);
                     else if (P->integrator == ZDRO_DIRECT) rad = direct_walk(s, P, material, ray, &smp, 0, V3(0, 0, 0), &C);
-                    else rad = path_walk(s, P, material, ray, &smp, 0, 0, 0, &C);
+                    else rad = path_walk(s, P, material, ray, &smp, 0, 0, 0, &C, 0);
                     if (!vany_nan(rad)) { /* integrator.py:27-28 */
                         sum.x += clampf(rad.x, 0.0f, 100000.0f); sum.y += clampf(rad.y, 0.0f, 100000.0f); sum.z += clampf(rad.z, 0.0f, 100000.0f);
                     } else C.c[C_NAN]++;
@@ -1060,4 +1137,8 @@ int zdro_render_backward(const zdro_scene *s, const zdro_params *P, const float 
     free(dm);
     if (counters) memcpy(counters, total.c, sizeof total.c);
     return 0;
+}
+
+float zdro_ggx_dlnpdf_dr(const float wo[3], const float wi[3], float r) {
+    return ggx_dlnpdf_dr(V3(wo[0], wo[1], wo[2]), V3(wi[0], wi[1], wi[2]), r);
 }

@@ -22,9 +22,10 @@ extern "C" {
 
 enum { ZDRO_COLLOCATED = 0, ZDRO_DIRECT = 1, ZDRO_PATH = 2, ZDRO_UVGRAD = 3 /* render_duvdxy, uvgrad.py */ };
 enum { ZDRO_SAMPLER_CMJ = 0, ZDRO_SAMPLER_PMJ02BN = 1 };
-/* PRB BSDF-sample adjoint form: corrected or the literal
- * weight of prb.py:162 (kept only to document the deviation). */
-enum { ZDRO_PRB_CORRECT = 0, ZDRO_PRB_LITERAL = 1 };
+/* PRB adjoint form: CORRECT = derivative of the forward's expectation (SURVEY App. A.7 plus the
+ * Russian-roulette renormalisation terms, see path_backward); LITERAL = the weight of prb.py:162;
+ * DETACHED = App. A.7 with every RR factor held constant.  The last two only document deviations. */
+enum { ZDRO_PRB_CORRECT = 0, ZDRO_PRB_LITERAL = 1, ZDRO_PRB_DETACHED = 2 };
 
 typedef struct zdro_scene zdro_scene;
 
@@ -90,6 +91,7 @@ void zdro_ggx_sample(const float wo[3], float roughness, float u_lobe, const flo
 /* reverse-mode derivative of ggx_brdf w.r.t. (diffuse rgb, roughness) for cotangent g */
 void zdro_ggx_brdf_grad(const float wo[3], const float wi[3], const float diffuse[3], float roughness,
                         const float g[3], float out[4]);
+float zdro_ggx_dlnpdf_dr(const float wo[3], const float wi[3], float r);
 void zdro_generate_ray(const zdro_params *, float px, float py, float o[3], float d[3]);
 void zdro_offset_ray_origin(const float p[3], const float n[3], float out[3]);
 void zdro_read_bsdf(const float *material, int tex_h, int tex_w, float u, float v, float out[4]);

@@ -55,7 +55,7 @@ ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io,
     GgxTerms g = ggx_terms(wo, wo, m.w);
     float inv_t = rcp(h.t), li = inv_t * inv_t;
     if (BWD) {
-        grad = brdf_grad(wo.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, m.w), le_grad * li);
+        float dl_; grad = brdf_grad(wo.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, wo, m.w, dl_), le_grad * li);
         guv = it.uv;
     }
     return ggx_brdf_from(g, wo, mk3(m.x, m.y, m.z)) * li;
@@ -125,7 +125,7 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
         radiance = radiance + ((bsdf * mis) * light.eval) * inv_dn;
         if (BWD) {
             f3 W = (light.eval * mis) * inv_dn;
-            float4 gr = brdf_grad(wil.z * ZDR_INV_PI, ggx_dfdr_from(g, wil, roughness), W * le_grad);
+            float dl_; float4 gr = brdf_grad(wil.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, wil, roughness, dl_), W * le_grad);
             mat_grad.x += gr.x; mat_grad.y += gr.y; mat_grad.z += gr.z; mat_grad.w += gr.w;
         }
     }
@@ -153,7 +153,7 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
                     COUNT(C_EMIT_BSDF);
                     radiance = radiance + (beta * mis) * em;
                     if (BWD) {
-                        float4 gr = brdf_grad(wi_local.z * ZDR_INV_PI, ggx_dfdr_from(g, wi_local, roughness), (em * (mis * inv_p)) * le_grad);
+                        float dl_; float4 gr = brdf_grad(wi_local.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, wi_local, roughness, dl_), (em * (mis * inv_p)) * le_grad);
                         mat_grad.x += gr.x; mat_grad.y += gr.y; mat_grad.z += gr.z; mat_grad.w += gr.w;
                     }
                 }
@@ -171,8 +171,12 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
 struct PathVertex {
     f2 uv;
     f3 bW;  float cL, dfLdr;     // beta_k * W_k;  wiL.z/pi;  d(f^L cos)/dr      (0 when NEE rejected)
+    f3 neeM;                     // beta_k f^L W_k * [pdf_bsdf/(pdf_light+pdf_bsdf) * dln(pdf_bsdf)/dr]: -d(MIS weight)/dr of the NEE term
     f3 bpq; float c, dfdr;       // beta_k/(p_k q_k);  wi.z/pi;  d(f cos)/dr     (0 when the path stops here)
     f3 T, fLW;                   // f_k/(p_k q_k);  f^L_k * W_k
+    float dlnp;                  // dln(pdf_bsdf)/dr of the sampled direction
+    int rr;                      // Russian roulette at this vertex: 0 none / q = 0.05, 1 stochastic (0.05 <= lum < 1), 2 renormalising (lum >= 1)
+    f3 bnorm;                    // beta leaving the vertex when rr == 2
 };
 
 // Per-lane path state of the flat loop.
@@ -188,7 +192,7 @@ struct PathState {
 // shaded, and sets term_Li when the path ended on an emitter.
 template <int SK, class A, bool BWD, bool STATS>
 ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                    PathState &ps, PathVertex &pv, bool &has_vertex, f3 &term_Li, Counters &cnt) {
+                    PathState &ps, PathVertex &pv, bool &has_vertex, f3 &term_Li, Counters &cnt, float *term_plfrac = nullptr) {
     has_vertex = false;
     COUNT(C_CLOSEST);
     Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
@@ -201,7 +205,8 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
         float pdf_light = sample_light_pdf(S, ps.o, it.inst, h.slot, it.p);
         float mis = balanced_heuristic(ps.pdf_bsdf, pdf_light);
         ps.L = ps.L + (ps.beta * mis) * em;
-        if (BWD) term_Li = em * mis;
+        if (BWD) { term_Li = em * mis;
+                   if (term_plfrac) *term_plfrac = (ps.pdf_bsdf + pdf_light > 1e-4f) ? pdf_light * rcp(ps.pdf_bsdf + pdf_light) : 0.0f; }
         if (STATS && ps.depth > 0) cnt.c[C_EMIT_BSDF]++;
         return true;
     }
@@ -212,7 +217,7 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     if (BWD) {
         has_vertex = true;
         pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
-        pv.T = mk3(0.0f); pv.fLW = mk3(0.0f);
+        pv.T = mk3(0.0f); pv.fLW = mk3(0.0f); pv.bnorm = mk3(0.0f); pv.neeM = mk3(0.0f); pv.dlnp = 0.0f; pv.rr = 0;
     }
     Onb onb = make_onb(it.ns);
     f3 wo = to_local(onb, -ps.d);
@@ -232,8 +237,11 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
         ps.L = ps.L + (((ps.beta * bsdf) * mis) * light.eval) * inv_dn;
         if (BWD) {
             f3 W = (light.eval * mis) * inv_dn;
-            pv.bW = ps.beta * W; pv.cL = wil.z * ZDR_INV_PI; pv.dfLdr = ggx_dfdr_from(g, wil, roughness);
+            float dlnpL;
+            pv.bW = ps.beta * W; pv.cL = wil.z * ZDR_INV_PI; pv.dfLdr = ggx_dfdr_from(g, wo, wil, roughness, dlnpL);
             pv.fLW = bsdf * W;
+            float pbf = (light.pdf + pb > 1e-4f) ? pb * rcp(light.pdf + pb) : 0.0f;   // d w_nee/dr = -w_nee pb/(pl+pb) dln(pb)/dr
+            pv.neeM = ((ps.beta * bsdf) * W) * (pbf * dlnpL);
         }
     }
     // BSDF sampling (prb.py:69-76)
@@ -246,6 +254,7 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     bool stop = (dot(wi, it.ng) < 1e-4f) || (wi_local.z < 1e-4f);                 // prb.py:73-74
     f3 beta_in = ps.beta;
     float q = 1.0f;
+    int rr_kind = 0;
     if (!stop) {
         ps.o = offset_ray_origin(it.p, it.ng); ps.d = wi;
         f3 f = ggx_brdf_from(g, wi_local, diffuse);
@@ -258,13 +267,18 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
                 q = fmaxf(l, 0.05f);
                 float r = sampler_next<SK>(C, ps.smp);
                 if (r >= q) stop = true;
-                else ps.beta = ps.beta * rcp(q);
+                else { ps.beta = ps.beta * rcp(q); rr_kind = (l >= 1.0f) ? 2 : ((l >= 0.05f) ? 1 : 0); }
             }
         }
         if (BWD && !stop) {
             float inv_pq = inv_p * rcp(q);
-            pv.bpq = beta_in * inv_pq; pv.c = wi_local.z * ZDR_INV_PI; pv.dfdr = ggx_dfdr_from(g, wi_local, roughness);
+            pv.bpq = beta_in * inv_pq; pv.c = wi_local.z * ZDR_INV_PI; pv.dfdr = ggx_dfdr_from(g, wo, wi_local, roughness, pv.dlnp);
             pv.T = f * inv_pq;
+            // prb.py:83 has no upper clamp on q: for lum(beta') >= 1 the path survives with certainty and is
+            // STILL divided by q = lum(beta'), i.e. beta leaves this vertex with unit luminance.  The forward's
+            // expectation then depends on q(material); the sweep differentiates through it (sweep_vertex).
+            pv.rr = rr_kind;
+            if (rr_kind == 2) pv.bnorm = ps.beta;
         }
     }
     ps.depth++;
@@ -272,31 +286,56 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     return stop;
 }
 
-// The vertex as the sweep stores it: 16 floats = four float4 (one LDS / scratch line per lane).
-// The NEE part of the gradient does not depend on the rest of the path, so it is contracted with the
-// pixel cotangent g at once; the BSDF part keeps only what multiplies Li:
-//   a = d f^L[bW g]                      (4)   NEE gradient of this vertex
-//   b = {Q = bpq g c, r = dfdr / c}      (4)   BSDF gradient = (Q Li, r sum(Q Li))
-//   c = {T, uv.x}, d = {A = fLW, uv.y}   (8)   Li_k = A + T Li_{k+1}
-struct PackedVertex { float4 a, b, c, d; };
+// The vertex as the sweep stores it: four float4 (+ a fifth for vertices at depth >= rr_depth).  The NEE
+// part of the gradient does not depend on the rest of the path, so it is finished at once (contracted
+// with the pixel cotangent g, MIS-weight derivative included); the BSDF part keeps what multiplies the
+// arriving adjoint:
+//   a = d f^L[bW g] - (0,0,0,<g, neeM>)  (4)   NEE gradient of this vertex
+//   b = {Q = bpq c, r = dfdr / c}        (4)   BSDF gradient = (Q Aeff, r sum(Q Aeff))
+//   c = {T, uv.x}, d = {g fLW, uv.y}     (8)   A_k = g fLW + T Aeff
+//   e = {b = beta leaving (rr == 2) | (-1,0,0) (rr == 1) | 0, dln(pdf)/dr}
+struct PackedVertex { float4 a, b, c, d, e; };
 
 ZD PackedVertex pack_vertex(const PathVertex &v, f3 g) {
     PackedVertex p;
     p.a = brdf_grad(v.cL, v.dfLdr, v.bW * g);
-    f3 Q = (v.bpq * g) * v.c;
+    p.a.w -= dot(g, v.neeM);
+    f3 Q = v.bpq * v.c;
     float r = (v.c > 0.0f) ? v.dfdr * rcp(v.c) : 0.0f;
     p.b = make_float4(Q.x, Q.y, Q.z, r);
     p.c = make_float4(v.T.x, v.T.y, v.T.z, v.uv.x);
-    p.d = make_float4(v.fLW.x, v.fLW.y, v.fLW.z, v.uv.y);
+    f3 gA = g * v.fLW;
+    p.d = make_float4(gA.x, gA.y, gA.z, v.uv.y);
+    f3 e = (v.rr == 2) ? v.bnorm : ((v.rr == 1) ? mk3(-1.0f, 0.0f, 0.0f) : mk3(0.0f));
+    p.e = make_float4(e.x, e.y, e.z, v.dlnp);
     return p;
 }
 
-// One step of the adjoint sweep (prb.py:105-187, corrected weight App. B-3): consumes a vertex,
-// carries Li one vertex towards the camera and returns that vertex's material gradient.
-ZD float4 sweep_vertex(const PackedVertex &p, f3 &Li, f2 &uv) {
-    f3 ct = mk3(p.b.x, p.b.y, p.b.z) * Li;
-    float4 g = make_float4(p.a.x + ct.x, p.a.y + ct.y, p.a.z + ct.z, p.a.w + p.b.w * (ct.x + ct.y + ct.z));
-    Li = mk3(p.d.x, p.d.y, p.d.z) + mk3(p.c.x, p.c.y, p.c.z) * Li;
+// Carriers of the adjoint sweep (deviation 8; derivation in oracle/zdr_oracle.c path_backward):
+//   A  adjoint of the scalar <g, L> w.r.t. the throughput (g-contracted: renormalisation mixes channels)
+//   Lv plain arriving radiance times g (the VALUE of what follows, for the score term)
+//   s  adjoint of the survival probability;  Z  <b, Lv> of the renormalisation whose 1/pdf this vertex lost
+//   tw once: d(MIS weight)/dr factor of the emitter hit that ended the path
+struct SweepState { f3 A, Lv; float s, Z, tw; };
+
+// One step (prb.py:105-187 with the corrected weight, App. B-3): consumes a vertex, returns its gradient.
+ZD float4 sweep_vertex(const PackedVertex &p, SweepState &S, f2 &uv) {
+    const f3 w = mk3(0.212671f, 0.715160f, 0.072169f);           // prb.py:80
+    f3 Aeff = S.A;
+    if (p.e.x < 0.0f) {                                          // stochastic RR vertex
+        Aeff = S.A + w * S.s; S.s = 0.0f; S.Z = 0.0f;
+    } else if (p.e.x + p.e.y + p.e.z > 0.0f) {                   // renormalising RR vertex
+        f3 b = mk3(p.e.x, p.e.y, p.e.z);
+        float ba = dot(b, S.A);
+        Aeff = S.A - w * ba; S.s += ba; S.Z = dot(b, S.Lv);
+    }
+    f3 ct = mk3(p.b.x, p.b.y, p.b.z) * Aeff;
+    float4 g = make_float4(p.a.x + ct.x, p.a.y + ct.y, p.a.z + ct.z,
+                           p.a.w + p.b.w * (ct.x + ct.y + ct.z) + p.e.w * (S.Z + S.tw));
+    S.tw = 0.0f;
+    f3 T = mk3(p.c.x, p.c.y, p.c.z), gA = mk3(p.d.x, p.d.y, p.d.z);
+    S.A = gA + T * Aeff;
+    S.Lv = gA + T * S.Lv;
     uv.x = p.c.w; uv.y = p.d.w;
     return g;
 }

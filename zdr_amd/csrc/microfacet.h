@@ -60,7 +60,9 @@ ZD float ggx_pdf_from(const GgxTerms &g, f3 wo, f3 wi) {
 // d(f cos)/d roughness, identical for the three channels:
 //   4 r^3 F wi.z / (4 ci co) (D' G + D (G1i' G1o + G1i G1o')),  D' = (1 - c(1 + a2)) / (pi t^3),
 //   G1' = -k / (s (1 + s)^2).  d(f cos)_c / d diffuse_c = wi.z / pi.
-ZD float ggx_dfdr_from(const GgxTerms &g, f3 wi, float roughness) {
+// Also returns d ln(ggx_sample_pdf) / d roughness (only the glossy half G1(wo) D / (4 |wo.z|) depends on
+// it): the PRB adjoint needs it where Russian roulette renormalises the throughput (integrators.h).
+ZD float ggx_dfdr_from(const GgxTerms &g, f3 wo, f3 wi, float roughness, float &dlnpdf_dr) {
     float t3 = g.t * g.t * g.t;
     float dD = (1.0f - g.nh2 * (1.0f + g.a2)) * rcp(ZDR_PI * t3);
     float opi = 1.0f + g.si, opo = 1.0f + g.so;
@@ -68,6 +70,8 @@ ZD float ggx_dfdr_from(const GgxTerms &g, f3 wi, float roughness) {
     float dG1o = -g.ko * rcp(g.so * (opo * opo));
     float dS = dD * (g.G1i * g.G1o) + g.D * (dG1i * g.G1o + g.G1i * dG1o);
     float r3 = roughness * roughness * roughness;
+    float dglossy = (dG1o * g.D + g.G1o * dD) * rcp(4.0f * fabsf(wo.z));
+    dlnpdf_dr = (0.5f * dglossy * 4.0f * r3) * rcp(ggx_pdf_from(g, wo, wi));
     return 4.0f * r3 * (g.F * wi.z * g.inv4) * dS;
 }
 

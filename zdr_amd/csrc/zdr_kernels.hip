@@ -108,12 +108,13 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
 }
 
 // PRB backward with ONE traversal.  Each trip a live lane advances its path by one bounce and
-// appends the shaded vertex (64 packed bytes) to its record list: the first ZDR_LDS_VERTICES
-// vertices live in LDS laid out [slot][float4][lane] (conflict-free ds_*_b128), deeper ones (5 % of
-// all vertices on cbox) in per-lane scratch.  When a path ends, a short wave-uniform loop sweeps its
-// records last to first (carrying Li) and queues the gradients; all queue traffic happens at
-// reconverged points so the whole wave takes part in a flush.  Keeping the records out of scratch is
-// what matters: 2.3 KB of scratch per lane thrashed L2 (113 GB of fabric traffic per launch, 13 of 37 ms).
+// appends the shaded vertex to its record list: vertices before the first Russian-roulette depth (at
+// most ZDR_LDS_VERTICES of them) live in LDS laid out [slot][float4][lane] (conflict-free ds_*_b128,
+// 4 float4 + one float), deeper ones (25 % of all vertices on cbox) in per-lane scratch (5 float4).
+// When a path ends, a short wave-uniform loop sweeps its records last to first and queues the
+// gradients; all queue traffic happens at reconverged points so the whole wave takes part in a flush.
+// Keeping the records out of scratch is what matters: 2.3 KB of scratch per lane thrashed L2 (113 GB of
+// fabric traffic per launch, 13 of 37 ms).
 #ifndef ZDR_LDS_VERTICES
 #define ZDR_LDS_VERTICES 2
 #endif
@@ -122,17 +123,19 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path_bwd(DScene S, Rend
     extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
     __shared__ float4 lds_rec[ZDR_LDS_VERTICES * 4 * WAVE];
+    __shared__ float lds_dlnp[ZDR_LDS_VERTICES * WAVE];
     const int lane = threadIdx.x;
+    const int lds_vertices = (R.rr_depth < ZDR_LDS_VERTICES) ? max(R.rr_depth, 0) : ZDR_LDS_VERTICES;   // LDS records carry no RR fields
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     Counters cnt;
     const f3 le_grad = load_le_grad(C, io, w);
     ScatterQueue q = scatter_queue_init(lds_q);
-    PackedVertex deep[ZDR_MAX_RECORDED_DEPTH - ZDR_LDS_VERTICES];
+    PackedVertex deep[ZDR_MAX_RECORDED_DEPTH];
     int nrec = 0;
     f3 term_Li = mk3(0.0f);
     int sw_k = -1;                                          // next vertex the sweep consumes
-    f3 sw_Li = mk3(0.0f);
+    SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
     uint32_t it = w.s_begin;
     bool alive = false;
     PathState ps;
@@ -148,35 +151,41 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path_bwd(DScene S, Rend
         }
         if (__ballot(alive) == 0ull) break;
         if (alive) {
-            PathVertex pv; bool has_vertex;
-            bool done = path_bounce<SK, A, true, false>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt);
+            PathVertex pv; bool has_vertex; float term_plfrac = 0.0f;
+            bool done = path_bounce<SK, A, true, false>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt, &term_plfrac);
             if (has_vertex) {
                 PackedVertex p = pack_vertex(pv, le_grad);
-                if (nrec < ZDR_LDS_VERTICES) {
+                if (nrec < lds_vertices) {
                     float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
                     r[0] = p.a; r[WAVE] = p.b; r[2 * WAVE] = p.c; r[3 * WAVE] = p.d;
-                } else deep[nrec - ZDR_LDS_VERTICES] = p;
+                    lds_dlnp[nrec * WAVE + lane] = p.e.w;
+                } else deep[nrec] = p;
                 nrec++;
             }
             if (done) {
                 alive = false;
-                if (!any_nan(ps.L) && nrec > 0) { sw_k = nrec - 1; sw_Li = term_Li; }   // prb.py:100: NaN paths contribute nothing
+                if (!any_nan(ps.L) && nrec > 0) {           // prb.py:100: NaN paths contribute nothing
+                    sw_k = nrec - 1;
+                    sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f;
+                    sw.tw = term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
+                }
             }
         }
         while (__ballot(sw_k >= 0) != 0ull) {               // wave-uniform: sweep every finished path to its first vertex
-            const bool sw = sw_k >= 0;
+            const bool swp = sw_k >= 0;
             float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             f2 guv; guv.x = 0.0f; guv.y = 0.0f;
-            if (sw) {
+            if (swp) {
                 PackedVertex p;
-                if (sw_k < ZDR_LDS_VERTICES) {
+                if (sw_k < lds_vertices) {
                     const float4 *r = lds_rec + (sw_k * 4) * WAVE + lane;
                     p.a = r[0]; p.b = r[WAVE]; p.c = r[2 * WAVE]; p.d = r[3 * WAVE];
-                } else p = deep[sw_k - ZDR_LDS_VERTICES];
-                g = sweep_vertex(p, sw_Li, guv);
+                    p.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[sw_k * WAVE + lane]);
+                } else p = deep[sw_k];
+                g = sweep_vertex(p, sw, guv);
                 sw_k--;
             }
-            scatter_push(q, io.cells, sw && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
+            scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
         }
     }
     scatter_flush(q, io.cells);

@@ -177,3 +177,32 @@ def test_uvgrad_matches_float64_ray_differences():
             np.testing.assert_allclose(img[y, x], exp, rtol=2e-4, atol=2e-6)
             checked += 1
     assert checked > 20
+
+
+def test_adjoint_follows_the_unclamped_russian_roulette(cbox_oracle):
+    """prb.py:83 divides by q = max(lum(beta), 0.05) without clamping q to 1: for lum(beta) >= 1 the
+    throughput is renormalised and the forward's expectation depends on q(material).  On a bright
+    material (albedo 0.8-0.98: lum(beta) >= 1 is the rule) the adjoint that keeps q constant is ~40 % off
+    finite differences; PRB_CORRECT follows them (deviation 8)."""
+    rng = np.random.default_rng(0)
+    m = np.empty((128, 128, 4), np.float32)
+    m[..., :3] = rng.uniform(0.8, 0.98, (128, 128, 3)); m[..., 3] = rng.uniform(0.3, 0.9, (128, 128))
+    W, spp = 16, 1024
+    wimg = rng.uniform(0.5, 1.5, (W, W, 4)).astype(np.float32); wimg[..., 3] = 0
+    delta = np.zeros_like(m); delta[..., :3] = rng.uniform(0, 1, m.shape[:2] + (3,))
+    res = {}
+    for mode in (oracle.PRB_CORRECT, oracle.PRB_DETACHED):
+        ad = []
+        for s in range(3):
+            p = oracle.make_params("path", W, W, spp, 100 + s, CBOX_CAMERA, m.shape[:2], prb_mode=mode)
+            ad.append((cbox_oracle.render_backward(p, wimg, m).astype(np.float64) * delta).sum())
+        res[mode] = np.mean(ad)
+    fd = []
+    for s in range(6):
+        p = oracle.make_params("path", W, W, spp, 300 + s, CBOX_CAMERA, m.shape[:2])
+        ip = cbox_oracle.render_forward(p, (m + 0.01 * delta).astype(np.float32)).astype(np.float64)
+        im = cbox_oracle.render_forward(p, (m - 0.01 * delta).astype(np.float32)).astype(np.float64)
+        fd.append(((ip - im) * wimg).sum() / 0.02)
+    fd_mean, fd_se = np.mean(fd), np.std(fd, ddof=1) / np.sqrt(len(fd))
+    assert abs(res[oracle.PRB_CORRECT] - fd_mean) < max(4 * fd_se, 0.02 * abs(fd_mean)), (res, fd_mean, fd_se)
+    assert abs(res[oracle.PRB_DETACHED] - fd_mean) > 0.2 * abs(fd_mean), (res, fd_mean)

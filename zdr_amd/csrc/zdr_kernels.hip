@@ -9,8 +9,13 @@
 #include "zdr.h"
 
 #define WAVE 64
+// __launch_bounds__ second argument = minimum waves per SIMD (caps the VGPR budget at 512 / n).
+// Measured on cbox 512^2 spp 256 (profiles/r1_ab_flags.txt): 3 (<= 168 VGPRs, no spills) is best for both.
 #ifndef ZDR_MIN_WAVES
-#define ZDR_MIN_WAVES 4   // <=128 VGPRs: 4 waves per SIMD measured best (profiles/r1_ab_flags.txt)
+#define ZDR_MIN_WAVES 3
+#endif
+#ifndef ZDR_MIN_WAVES_BWD
+#define ZDR_MIN_WAVES_BWD ZDR_MIN_WAVES
 #endif
 
 struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk; };
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
 #define ZDR_LDS_VERTICES 2
 #endif
 template <int SK, class A>
-__global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
     __shared__ float4 lds_rec[ZDR_LDS_VERTICES * 4 * WAVE];

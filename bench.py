@@ -153,6 +153,15 @@ def main():
                          "bytes_per_sample": {"fwd": round(a_fwd, 1), "bwd": round(a_bwd, 1)},
                          "fwd_achieved": round(a_fwd * n_per_pass / (fwd_ms * 1e-3) / 1e9, 2)},
         }
+        try:   # gradient accuracy against finite differences: measured by tools/fd_validate.py / tools/fd_directional.py
+            fdv = json.load(open(os.path.join(ROOT, "profiles", "r1_fd_validate_diffuse_texel.json")))["tail"]
+            fdd = json.load(open(os.path.join(ROOT, "profiles", "r1_fd_directional.json")))["result"]
+            out["grad_rel_err_vs_fd"] = {
+                "fd_validate_procedure_single_pixel_texel": {"rel_err": fdv["rel_err"], "one_sigma": fdv["one_sigma"], "spp": fdv["spp"], "seeds": fdv["seeds"]},
+                "whole_image_directional": {k: {"rel_err": v["rel_err"], "one_sigma": v["one_sigma"]} for k, v in fdd.items()},
+                "source": "profiles/r1_fd_validate_diffuse_texel.json, profiles/r1_fd_directional.json (FD eps 0.01, same-seed renders)"}
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, mat_np, W, args.cpu_spp)
         print(json.dumps(out))

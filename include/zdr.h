@@ -83,6 +83,14 @@ int zdr_scene_info(const zdr_scene *scene, zdr_scene_info_t *info);
 /* Replaces Scene.update_lights (render.py:130-148). HOST input ninst x 3; rebuilds the light list. */
 int zdr_scene_set_emissions(zdr_scene *scene, const float *inst_emission, void *stream);
 
+/* Replaces Scene.add_envmap / load_envmap (render.py:150-156, envmap.py:116-203): a lat-long environment
+ * light.  HOST inputs, copied to the device: tex (tex_h x tex_w x 4 float32, already made square as
+ * envmap.py:123-128 does) and the importance-sampling tables the host builds from it (zdr_amd/envmap.py:
+ * alias_prob / alias_idx hold the marginal p(y) table (map_h entries) followed by map_h conditional p(x|y)
+ * tables of map_w entries; pdf is map_h x map_w).  tex == NULL removes the environment (env_count = 0). */
+int zdr_scene_set_envmap(zdr_scene *scene, const float *tex, uint32_t tex_h, uint32_t tex_w, const float *alias_prob,
+                         const int32_t *alias_idx, const float *pdf, uint32_t map_w, uint32_t map_h);
+
 /* Tables of the PMJ02bn sampler (pmj02bn.py:9-18; the reference's own are absent,
  * .MISSING_LARGE_BLOBS).  HOST inputs, copied to the device: pmj [nsets][nsamples][2] uint32
  * (value / 2^32), bn [ntex][res][res] uint16 (value / 2^16). */

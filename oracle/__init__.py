@@ -60,6 +60,7 @@ def lib(variant: str = "ieee"):
         L.zdro_scene_create.argtypes = [fp, C.c_int, ip, C.c_int, ip, fp, fp, C.c_int]
         L.zdro_scene_destroy.argtypes = [C.c_void_p]
         L.zdro_scene_set_emissions.argtypes = [C.c_void_p, fp]
+        L.zdro_scene_set_envmap.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, fp, ip, C.c_int, fp, C.c_int, C.c_int]
         L.zdro_render_forward.argtypes = [C.c_void_p, C.POINTER(Params), fp, fp, C.POINTER(C.c_uint64)]
         L.zdro_render_backward.argtypes = [C.c_void_p, C.POINTER(Params), fp, fp, fp, C.POINTER(C.c_uint64)]
         L.zdro_trace_closest.argtypes = [C.c_void_p, fp, C.c_int, ip, fp]
@@ -139,6 +140,11 @@ class OracleScene:
     def set_emissions(self, e):
         e = np.ascontiguousarray(e, np.float32).reshape(self.ninst, 3)
         self._L.zdro_scene_set_emissions(self.h, _f(e))
+
+    def set_envmap(self, tex, alias_prob, alias_idx, pdf, map_w=512, map_h=256):
+        tex = np.ascontiguousarray(tex, np.float32); ap = np.ascontiguousarray(alias_prob, np.float32)
+        ai = np.ascontiguousarray(alias_idx, np.int32); pd = np.ascontiguousarray(pdf, np.float32)
+        self._L.zdro_scene_set_envmap(self.h, _f(tex), tex.shape[0], tex.shape[1], _f(ap), _i(ai), ap.shape[0], _f(pd), map_w, map_h)
 
     def render_forward(self, params: Params, material: np.ndarray, counters: bool = False):
         material = np.ascontiguousarray(material, np.float32)

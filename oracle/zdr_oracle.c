@@ -62,6 +62,11 @@ struct zdro_scene {
     int32_t *tri_inst;  /* instance of each triangle */
     v3 *wp;             /* ntris x 3 world-space corner positions */
     float *planes;      /* ntris x 12: {n, n.p0} {nu, du} {nv, dv} (tri_planes) */
+    /* environment light (envmap.py): heap slots 23330 (alias tables), 23331 (pdf), 23332 (texture) */
+    int env_count, env_h, env_w, map_w, map_h;
+    float *env_tex;     /* env_h x env_w x 4 */
+    float *alias_prob; int32_t *alias_idx;   /* [map_h] marginal p(y), then map_h tables of map_w: p(x|y) */
+    float *env_pdf;     /* map_h x map_w */
 };
 
 static void tri_planes(const v3 *p, float *out);
@@ -135,7 +140,23 @@ zdro_scene *zdro_scene_create(const float *verts, int nverts, const int32_t *tri
 void zdro_scene_destroy(zdro_scene *s) {
     if (!s) return;
     free(s->verts); free(s->tris); free(s->tri_begin); free(s->xform); free(s->nmat);
-    free(s->emission); free(s->light_insts); free(s->tri_inst); free(s->wp); free(s->planes); free(s);
+    free(s->emission); free(s->light_insts); free(s->tri_inst); free(s->wp); free(s->planes);
+    free(s->env_tex); free(s->alias_prob); free(s->alias_idx); free(s->env_pdf); free(s);
+}
+
+/* Scene.add_envmap / load_envmap (render.py:150-156, envmap.py:116-203): the tables come from the host
+ * (zdr_amd/envmap.py); tex == NULL removes the environment. */
+void zdro_scene_set_envmap(zdro_scene *s, const float *tex, int tex_h, int tex_w, const float *alias_prob,
+                           const int32_t *alias_idx, int n_alias, const float *pdf, int map_w, int map_h) {
+    free(s->env_tex); free(s->alias_prob); free(s->alias_idx); free(s->env_pdf);
+    s->env_tex = 0; s->alias_prob = 0; s->alias_idx = 0; s->env_pdf = 0; s->env_count = 0;
+    if (!tex) return;
+    s->env_h = tex_h; s->env_w = tex_w; s->map_w = map_w; s->map_h = map_h;
+    s->env_tex = (float *)malloc(sizeof(float) * 4 * (size_t)tex_h * tex_w); memcpy(s->env_tex, tex, sizeof(float) * 4 * (size_t)tex_h * tex_w);
+    s->alias_prob = (float *)malloc(sizeof(float) * n_alias); memcpy(s->alias_prob, alias_prob, sizeof(float) * n_alias);
+    s->alias_idx = (int32_t *)malloc(sizeof(int32_t) * n_alias); memcpy(s->alias_idx, alias_idx, sizeof(int32_t) * n_alias);
+    s->env_pdf = (float *)malloc(sizeof(float) * (size_t)map_w * map_h); memcpy(s->env_pdf, pdf, sizeof(float) * (size_t)map_w * map_h);
+    s->env_count = 1;
 }
 
 void zdro_scene_set_emissions(zdro_scene *s, const float *e) {
@@ -643,6 +664,61 @@ static int v4_any_nonzero(v4 g) { return g.x != 0 || g.y != 0 || g.z != 0 || g.w
 /* ------------------------------------------------------------------ lights */
 typedef struct { v3 wi; float dist, pdf; v3 eval; } light_sample_t; /* light.py:11 */
 
+/* heap.texture2d_sample(23332, uv) — LuisaCompute, "default filter & address mode" (envmap.py:130),
+ * unpinned: bilinear between texel centres, clamp to edge (same in zdr_amd/envmap.py and the kernels) */
+static v3 env_lookup(const zdro_scene *s, v2 uv) {
+    float x = uv.x * (float)s->env_w - 0.5f, y = uv.y * (float)s->env_h - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    int x0 = clampi((int)x0f, 0, s->env_w - 1), x1 = clampi((int)x0f + 1, 0, s->env_w - 1);
+    int y0 = clampi((int)y0f, 0, s->env_h - 1), y1 = clampi((int)y0f + 1, 0, s->env_h - 1);
+    const float *c00 = s->env_tex + 4 * ((size_t)y0 * s->env_w + x0), *c10 = s->env_tex + 4 * ((size_t)y0 * s->env_w + x1);
+    const float *c01 = s->env_tex + 4 * ((size_t)y1 * s->env_w + x0), *c11 = s->env_tex + 4 * ((size_t)y1 * s->env_w + x1);
+    float r[3];
+    for (int k = 0; k < 3; k++) {
+        float top = c00[k] + (c10[k] - c00[k]) * fx, bot = c01[k] + (c11[k] - c01[k]) * fx;
+        r[k] = top + (bot - top) * fy;
+    }
+    return V3(r[0], r[1], r[2]);
+}
+static v3 uv_to_direction(v2 uv) { /* envmap.py:206-214 */
+    float phi = 2.0f * PI_F * (1.0f - uv.x), theta = PI_F * uv.y;
+    float y = cosf(theta), st = sinf(theta);
+    return vnormalize(V3(sinf(phi) * st, y, cosf(phi) * st));
+}
+static v2 direction_to_uv(v3 d) { /* envmap.py:216-220 */
+    v2 uv; uv.x = 1.0f - atan2f(d.x, d.z) / (2.0f * PI_F); uv.y = acosf(d.y) / PI_F;
+    return uv;
+}
+static void sample_alias_table(const zdro_scene *s, int n, float u_in, int offset, int *index, float *uu) { /* envmap.py:85-106 */
+    float u = u_in * (float)n;
+    int i = clampi((int)u, 0, n - 1);
+    float ur = u - floorf(u);
+    float prob = s->alias_prob[i + offset];
+    if (ur < prob) { *index = i; *uu = ur / prob; }
+    else { *index = s->alias_idx[i + offset]; *uu = (ur - prob) / (1.0f - prob); }
+}
+/* n = number of lights the light sampler chooses from: the reference forgets the 1/n for the environment
+ * (envmap.py:236) and for sample_light_pdf (light.py:89) — SURVEY App. B-9 "fix when envmap lands" */
+static light_sample_t sample_envmap(const zdro_scene *s, v2 u, int n) { /* envmap.py:223-238 */
+    int iy, ix; float uy, ux;
+    sample_alias_table(s, s->map_h, u.y, 0, &iy, &uy);
+    sample_alias_table(s, s->map_w, u.x, s->map_h + iy * s->map_w, &ix, &ux);
+    v2 uv; uv.x = ((float)ix + ux) / (float)s->map_w; uv.y = ((float)iy + uy) / (float)s->map_h;
+    float pdf = s->env_pdf[iy * s->map_w + ix];
+    light_sample_t L;
+    L.wi = uv_to_direction(uv); L.dist = 1e30f;
+    float sn = sinf(PI_F * uv.y), inv_s = sn > 0 ? 1.0f / sn : 0.0f;
+    L.pdf = pdf * inv_s / (2.0f * PI_F * PI_F) / (float)n;
+    L.eval = env_lookup(s, uv);
+    return L;
+}
+static float env_sampled_light_pdf(const zdro_scene *s, v3 dir, int n) { /* envmap.py:240-248 */
+    v2 uv = direction_to_uv(dir);
+    int index = clampi((int)(uv.y * (float)s->map_h), 0, s->map_h - 1) * s->map_w + clampi((int)(uv.x * (float)s->map_w), 0, s->map_w - 1);
+    float sn = sinf(PI_F * uv.y), inv_s = sn > 0 ? 1.0f / sn : 0.0f;
+    return s->env_pdf[index] * inv_s / (2.0f * PI_F * PI_F) / (float)n;
+}
+
 static v3 sample_uniform_triangle(v2 u) { /* light.py:16-20 */
     v2 uv;
     if (u.x < u.y) { uv.x = 0.5f * u.x; uv.y = -0.5f * u.x + u.y; }
@@ -670,13 +746,15 @@ static float light_pdf_core(const zdro_scene *s, int n, int inst, int prim, v3 o
 static light_sample_t sample_light(const zdro_scene *s, v3 origin, sampler_t *smp) { /* light.py:23-81, mesh lights only */
     light_sample_t L; memset(&L, 0, sizeof L);
     float u = sampler_next(smp);
-    int n = s->light_count; /* env_count = 0, point_light_count = 0 (light.py:7) */
+    int n = s->env_count + s->light_count; /* point_light_count = 0 (light.py:7) */
     if (n <= 0) { /* reference would index out of bounds; consume the same dimensions, contribute nothing */
         (void)sampler_next(smp); (void)sampler_next2(smp);
         L.wi = V3(0, 0, 1); L.dist = 0; L.pdf = 1.0f; L.eval = V3(0, 0, 0);
         return L;
     }
     int idx = clampi((int)(u * (float)n), 0, n - 1);
+    if (idx < s->env_count) return sample_envmap(s, sampler_next2(smp), n); /* light.py:29-31: only next2f() is drawn */
+    idx -= s->env_count;
     int inst = s->light_insts[idx];
     int trig_count = s->tri_begin[inst + 1] - s->tri_begin[inst];
     int prim = clampi((int)(sampler_next(smp) * (float)trig_count), 0, trig_count - 1);
@@ -693,7 +771,7 @@ static light_sample_t sample_light(const zdro_scene *s, v3 origin, sampler_t *sm
 }
 
 static float sample_light_pdf(const zdro_scene *s, v3 origin, int inst, int prim, v3 p) { /* light.py:84-111 */
-    return light_pdf_core(s, s->light_count, inst, prim, origin, p, 0, 0, 0);
+    return light_pdf_core(s, s->env_count + s->light_count, inst, prim, origin, p, 0, 0, 0);
 }
 
 static float balanced_heuristic(float a, float b) { return a / fmaxf(a + b, 1e-4f); } /* prb.py:12-13 */
@@ -775,7 +853,7 @@ static v3 direct_walk(const zdro_scene *s, const zdro_params *P, const float *ma
                       double *dmat, v3 le_grad, counters_t *C) {
     C->c[C_CLOSEST]++;
     hit_t hit = trace_closest(s, &ray);
-    if (hit.inst < 0) return V3(0, 0, 0); /* env_count == 0 */
+    if (hit.inst < 0) return s->env_count > 0 ? env_lookup(s, direction_to_uv(ray.d)) : V3(0, 0, 0); /* direct.py:23-24 */
     C->c[C_HITS]++;
     interaction_t it = surface_interact(s, &hit);
     if (vdot(vneg(ray.d), it.ng) < 1e-4f || vdot(vneg(ray.d), it.ns) < 1e-4f) return V3(0, 0, 0);
@@ -812,13 +890,20 @@ static v3 direct_walk(const zdro_scene *s, const zdro_params *P, const float *ma
         v3 origin = it.p;
         C->c[C_CLOSEST]++;
         hit_t h2 = trace_closest(s, &r2);
-        if (h2.inst < 0) break; /* no envmap: emission 0 */
-        C->c[C_HITS]++;
-        interaction_t it2 = surface_interact(s, &h2);
-        if (vdot(vneg(r2.d), it2.ng) < 1e-4f || vdot(vneg(r2.d), it2.ns) < 1e-4f) break;
-        const float *e = s->emission + 3 * h2.inst;
+        float envc[3] = {0, 0, 0}; const float *e; float pdf_light;
+        if (h2.inst < 0) { /* direct.py:68-71 */
+            if (s->env_count <= 0) break;
+            v3 ev = env_lookup(s, direction_to_uv(r2.d));
+            envc[0] = ev.x; envc[1] = ev.y; envc[2] = ev.z; e = envc;
+            pdf_light = env_sampled_light_pdf(s, r2.d, s->env_count + s->light_count);
+        } else {
+            C->c[C_HITS]++;
+            interaction_t it2 = surface_interact(s, &h2);
+            if (vdot(vneg(r2.d), it2.ng) < 1e-4f || vdot(vneg(r2.d), it2.ns) < 1e-4f) break;
+            e = s->emission + 3 * h2.inst;
+            pdf_light = sample_light_pdf(s, origin, h2.inst, h2.prim, it2.p);
+        }
         if (e[0] > 0 || e[1] > 0 || e[2] > 0) {
-            float pdf_light = sample_light_pdf(s, origin, h2.inst, h2.prim, it2.p);
             float pdf_bsdf = ggx_sample_pdf(wo, wi_local, roughness);
             float mis = balanced_heuristic(pdf_bsdf, pdf_light);
             v3 beta = vdivs(ggx_brdf(wo, wi_local, diffuse, specular, roughness), pdf_bsdf);
@@ -863,7 +948,17 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
     for (int depth = 0; depth < max_depth; depth++) {
         C->c[C_CLOSEST]++;
         hit_t hit = trace_closest(s, &ray);
-        if (hit.inst < 0) break; /* env_count == 0 */
+        if (hit.inst < 0) { /* prb.py:26-32; written like direct.py:70-83 (prb.py is stale and squares beta) */
+            if (s->env_count > 0) {
+                v3 em = env_lookup(s, direction_to_uv(ray.d));
+                float pdf_light = env_sampled_light_pdf(s, ray.d, s->env_count + s->light_count);
+                float mis = balanced_heuristic(pdf_bsdf, pdf_light);
+                radiance = vadd(radiance, vmul(vscale(beta, mis), em));
+                if (terminal_Li) *terminal_Li = vscale(em, mis);
+                if (terminal_pl_frac) *terminal_pl_frac = (pdf_bsdf + pdf_light > 1e-4f) ? pdf_light / (pdf_bsdf + pdf_light) : 0.0f;
+            }
+            break;
+        }
         C->c[C_HITS]++;
         interaction_t it = surface_interact(s, &hit);
         if (vdot(vneg(ray.d), it.ng) < 1e-4f || vdot(vneg(ray.d), it.ns) < 1e-4f) break;

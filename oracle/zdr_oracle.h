@@ -40,6 +40,9 @@ zdro_scene *zdro_scene_create(const float *verts, int nverts, const int32_t *tri
                               const float *inst_emission, int ninst);
 void zdro_scene_destroy(zdro_scene *);
 void zdro_scene_set_emissions(zdro_scene *, const float *inst_emission); /* render.py:130-148 */
+/* Scene.add_envmap (render.py:150-156): texture (tex_h x tex_w x 4) + the tables of zdr_amd/envmap.py; tex NULL = none */
+void zdro_scene_set_envmap(zdro_scene *, const float *tex, int tex_h, int tex_w, const float *alias_prob,
+                           const int32_t *alias_idx, int n_alias, const float *pdf, int map_w, int map_h);
 
 /* Optional pbrt-v4 style tables for the PMJ02bn sampler (pmj02bn.py:9-18).
  * pmj: [nsets][nsamples][2] uint32 (value / 2^32); bn: [ntex][res][res] uint16 (/2^16).

@@ -22,7 +22,7 @@ COUNTER_NAMES = ("samples", "closest_rays", "closest_hits", "shadow_rays", "shad
 
 # every symbol include/zdr.h declares
 EXPORTS = ("zdr_version", "zdr_last_error", "zdr_scene_create", "zdr_scene_destroy", "zdr_scene_info",
-           "zdr_scene_set_emissions", "zdr_scene_set_pmj02bn_tables", "zdr_render_forward", "zdr_render_backward",
+           "zdr_scene_set_emissions", "zdr_scene_set_envmap", "zdr_scene_set_pmj02bn_tables", "zdr_render_forward", "zdr_render_backward",
            "zdr_render_stats", "zdr_trace_closest", "zdr_trace_any", "zdr_sampler_dump", "zdr_debug_build_accel")
 
 
@@ -72,6 +72,7 @@ def lib():
     L.zdr_scene_destroy.argtypes = [vp]
     L.zdr_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
     L.zdr_scene_set_emissions.argtypes = [vp, fp, vp]
+    L.zdr_scene_set_envmap.argtypes = [vp, fp, C.c_uint32, C.c_uint32, fp, ip, fp, C.c_uint32, C.c_uint32]
     L.zdr_scene_set_pmj02bn_tables.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32]
     L.zdr_render_forward.argtypes = [vp, C.POINTER(RenderParams), fp, fp, vp]
     L.zdr_render_backward.argtypes = [vp, C.POINTER(RenderParams), fp, fp, fp, vp]

@@ -93,12 +93,12 @@ ZD float4 uvgrad_sample(const DScene &S, int *lds, f3 o, f3 d, f3 odx, f3 ddx, f
 
 // -------------------------------------------------------------------------------- direct
 // direct.py:21-85 (forward) / 89-167 (adjoint; gradient written once at the primary uv, App. B-11)
-template <int SK, class A, bool BWD, bool STATS>
+template <int SK, class A, bool BWD, bool STATS, bool ENV>
 ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
                     Sampler &smp, f3 o, f3 d, f3 le_grad, Counters &cnt, f2 &guv, float4 &grad) {
     COUNT(C_CLOSEST);
     Hit h = A::closest(S, lds, o, d, 0.0f, 1e30f);
-    if (h.slot < 0) return mk3(0.0f);
+    if (h.slot < 0) return (ENV && S.env_count > 0) ? env_lookup(S, direction_to_uv(d)) : mk3(0.0f);   // direct.py:23-24
     COUNT(C_HITS);
     Interaction it = surface_interact(S, h);
     if (dot(-d, it.ng) < 1e-4f || dot(-d, it.ns) < 1e-4f) return mk3(0.0f);
@@ -108,9 +108,8 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     COUNT(C_SHADED);
     float4 mat_grad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     f3 radiance = mk3(0.0f);
-    float u_pick = sampler_next<SK>(C, smp), u_prim = sampler_next<SK>(C, smp);
-    f2 u_pt = sampler_next2<SK>(C, smp);
-    LightSample light = sample_light(S, it.p, u_pick, u_prim, u_pt);
+    float u_pick = sampler_next<SK>(C, smp);
+    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, smp); }, [&]() { return sampler_next2<SK>(C, smp); });
     COUNT(C_SHADOW);
     bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
     Onb onb = make_onb(it.ns);
@@ -138,25 +137,31 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
         f3 o2 = offset_ray_origin(it.p, it.ng);
         COUNT(C_CLOSEST);
         Hit h2 = A::closest(S, lds, o2, wi, 0.0f, 1e30f);
+        f3 em = mk3(0.0f); float pdf_light = 0.0f; bool lit = false;
         if (h2.slot >= 0) {
             COUNT(C_HITS);
             Interaction it2 = surface_interact(S, h2);
             if (!(dot(-wi, it2.ng) < 1e-4f || dot(-wi, it2.ns) < 1e-4f)) {
-                f3 em = ld3(S.emission + 3 * it2.inst);
-                if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {
-                    float pdf_light = sample_light_pdf(S, it.p, it2.inst, h2.slot, it2.p);   // origin = it.p (direct.py:66)
-                    GgxTerms g = ggx_terms(wo, wi_local, roughness);
-                    float pdf_bsdf = ggx_pdf_from(g, wo, wi_local);
-                    float mis = balanced_heuristic(pdf_bsdf, pdf_light);
-                    float inv_p = rcp(pdf_bsdf);
-                    f3 beta = ggx_brdf_from(g, wi_local, diffuse) * inv_p;
-                    COUNT(C_EMIT_BSDF);
-                    radiance = radiance + (beta * mis) * em;
-                    if (BWD) {
-                        float dl_; float4 gr = brdf_grad(wi_local.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, wi_local, roughness, dl_), (em * (mis * inv_p)) * le_grad);
-                        mat_grad.x += gr.x; mat_grad.y += gr.y; mat_grad.z += gr.z; mat_grad.w += gr.w;
-                    }
-                }
+                em = ld3(S.emission + 3 * it2.inst);
+                pdf_light = sample_light_pdf<ENV>(S, it.p, it2.inst, h2.slot, it2.p);   // origin = it.p (direct.py:66)
+                lit = true;
+            }
+        } else if (ENV && S.env_count > 0) {                                      // direct.py:68-71
+            em = env_lookup(S, direction_to_uv(wi));
+            pdf_light = env_sampled_light_pdf(S, wi, S.env_count + S.light_count);
+            lit = true;
+        }
+        if (lit && (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f)) {
+            GgxTerms g = ggx_terms(wo, wi_local, roughness);
+            float pdf_bsdf = ggx_pdf_from(g, wo, wi_local);
+            float mis = balanced_heuristic(pdf_bsdf, pdf_light);
+            float inv_p = rcp(pdf_bsdf);
+            f3 beta = ggx_brdf_from(g, wi_local, diffuse) * inv_p;
+            COUNT(C_EMIT_BSDF);
+            radiance = radiance + (beta * mis) * em;
+            if (BWD) {
+                float dl_; float4 gr = brdf_grad(wi_local.z * ZDR_INV_PI, ggx_dfdr_from(g, wo, wi_local, roughness, dl_), (em * (mis * inv_p)) * le_grad);
+                mat_grad.x += gr.x; mat_grad.y += gr.y; mat_grad.z += gr.z; mat_grad.w += gr.w;
             }
         }
     }
@@ -190,19 +195,29 @@ struct PathState {
 // Advance one live path by one bounce (prb.py:23-87 is the body of `for depth in range(max_depth)`).
 // Returns true when the path has terminated.  BWD: fills pv and sets has_vertex when a vertex was
 // shaded, and sets term_Li when the path ended on an emitter.
-template <int SK, class A, bool BWD, bool STATS>
+template <int SK, class A, bool BWD, bool STATS, bool ENV>
 ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
                     PathState &ps, PathVertex &pv, bool &has_vertex, f3 &term_Li, Counters &cnt, float *term_plfrac = nullptr) {
     has_vertex = false;
     COUNT(C_CLOSEST);
     Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
-    if (h.slot < 0) return true;                                                  // prb.py:26-32, env_count == 0
+    if (h.slot < 0) {                                                             // prb.py:26-32, in the form of direct.py:70-83
+        if (ENV && S.env_count > 0) {
+            f3 em = env_lookup(S, direction_to_uv(ps.d));
+            float pdf_light = env_sampled_light_pdf(S, ps.d, S.env_count + S.light_count);
+            float mis = balanced_heuristic(ps.pdf_bsdf, pdf_light);
+            ps.L = ps.L + (ps.beta * mis) * em;
+            if (BWD) { term_Li = em * mis;
+                       if (term_plfrac) *term_plfrac = (ps.pdf_bsdf + pdf_light > 1e-4f) ? pdf_light * rcp(ps.pdf_bsdf + pdf_light) : 0.0f; }
+        }
+        return true;
+    }
     COUNT(C_HITS);
     Interaction it = surface_interact(S, h);
     if (dot(-ps.d, it.ng) < 1e-4f || dot(-ps.d, it.ns) < 1e-4f) return true;      // prb.py:35-36
     f3 em = ld3(S.emission + 3 * it.inst);
     if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {                              // prb.py:39-44
-        float pdf_light = sample_light_pdf(S, ps.o, it.inst, h.slot, it.p);
+        float pdf_light = sample_light_pdf<ENV>(S, ps.o, it.inst, h.slot, it.p);
         float mis = balanced_heuristic(ps.pdf_bsdf, pdf_light);
         ps.L = ps.L + (ps.beta * mis) * em;
         if (BWD) { term_Li = em * mis;
@@ -222,9 +237,8 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     Onb onb = make_onb(it.ns);
     f3 wo = to_local(onb, -ps.d);
     // next-event estimation (prb.py:57-66)
-    float u_pick = sampler_next<SK>(C, ps.smp), u_prim = sampler_next<SK>(C, ps.smp);
-    f2 u_pt = sampler_next2<SK>(C, ps.smp);
-    LightSample light = sample_light(S, it.p, u_pick, u_prim, u_pt);
+    float u_pick = sampler_next<SK>(C, ps.smp);
+    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
     COUNT(C_SHADOW);
     bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
     f3 wil = to_local(onb, light.wi);

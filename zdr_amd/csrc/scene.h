@@ -25,6 +25,9 @@ struct DScene {
     const int32_t *inst_tri_begin;  // ninst + 1   (heap slot 23335 holds the counts)
     const int32_t *slot_of_tri;     // input triangle index -> slot
     int32_t ntris, ninst, light_count, nnodes;
+    // environment light (envmap.py; heap slots 23330-23332): lat-long RGBA texture + importance tables
+    const float4 *env_tex; const float *alias_prob; const int32_t *alias_idx; const float *env_pdf;
+    int32_t env_count, env_h, env_w, map_w, map_h;
     int32_t stack_entries;          // per-lane traversal stack entries this tree needs (dynamic LDS: entries x 64 ints per wave)
 };
 
@@ -164,15 +167,72 @@ ZD float light_pdf(f3 origin, f3 p, f3 ln, float area, int n_times_T, f3 &wi, fl
     return sqr_dist * rcp((float)n_times_T * area * cos_light);
 }
 
-// sample_light (light.py:23-81) for mesh lights; consumes next(), next(), next2f()
-ZD LightSample sample_light(const DScene &S, f3 origin, float u_pick, float u_prim, f2 u_pt) {
+// ------------------------------------------------------------------------ environment light
+// heap.texture2d_sample(23332, uv): bilinear between texel centres, clamp to edge (unpinned, see zdr_amd/envmap.py)
+ZD f3 env_lookup(const DScene &S, f2 uv) {
+    float x = uv.x * (float)S.env_w - 0.5f, y = uv.y * (float)S.env_h - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y), fx = x - x0f, fy = y - y0f;
+    int x0 = clampi((int)x0f, 0, S.env_w - 1), x1 = clampi((int)x0f + 1, 0, S.env_w - 1);
+    int y0 = clampi((int)y0f, 0, S.env_h - 1), y1 = clampi((int)y0f + 1, 0, S.env_h - 1);
+    float4 c00 = S.env_tex[(size_t)y0 * S.env_w + x0], c10 = S.env_tex[(size_t)y0 * S.env_w + x1];
+    float4 c01 = S.env_tex[(size_t)y1 * S.env_w + x0], c11 = S.env_tex[(size_t)y1 * S.env_w + x1];
+    f3 top = xyz(c00) + (xyz(c10) - xyz(c00)) * fx, bot = xyz(c01) + (xyz(c11) - xyz(c01)) * fx;
+    return top + (bot - top) * fy;
+}
+ZD f3 uv_to_direction(f2 uv) {                                   // envmap.py:206-214
+    float phi = 2.0f * ZDR_PI * (1.0f - uv.x), theta = ZDR_PI * uv.y;
+    float st = sinf(theta);
+    return normalize(mk3(sinf(phi) * st, cosf(theta), cosf(phi) * st));
+}
+ZD f2 direction_to_uv(f3 d) {                                    // envmap.py:216-220
+    f2 uv; uv.x = 1.0f - atan2f(d.x, d.z) * (1.0f / (2.0f * ZDR_PI)); uv.y = acosf(d.y) * ZDR_INV_PI;
+    return uv;
+}
+ZD void sample_alias_table(const DScene &S, int n, float u_in, int offset, int &index, float &uu) {   // envmap.py:85-106
+    float u = u_in * (float)n;
+    int i = clampi((int)u, 0, n - 1);
+    float ur = u - floorf(u);
+    float prob = S.alias_prob[i + offset];
+    if (ur < prob) { index = i; uu = ur * rcp(prob); }
+    else { index = S.alias_idx[i + offset]; uu = (ur - prob) * rcp(1.0f - prob); }
+}
+ZD float env_pdf_scale(float v, int n) {                         // 1 / (sin(pi v) 2 pi^2 n); App. B-9: 1/n added
+    float sn = sinf(ZDR_PI * v);
+    float inv_s = (sn > 0.0f) ? rcp(sn) : 0.0f;
+    return inv_s * rcp(2.0f * ZDR_PI * ZDR_PI * (float)n);
+}
+ZD float env_sampled_light_pdf(const DScene &S, f3 dir, int n) {  // envmap.py:240-248
+    f2 uv = direction_to_uv(dir);
+    int index = clampi((int)(uv.y * (float)S.map_h), 0, S.map_h - 1) * S.map_w + clampi((int)(uv.x * (float)S.map_w), 0, S.map_w - 1);
+    return S.env_pdf[index] * env_pdf_scale(uv.y, n);
+}
+
+// sample_light (light.py:23-81): u_pick = next() was drawn by the caller; the environment branch then
+// draws only next2f(), the mesh branch next() and next2f() (light.py:29-31 vs 50-63).
+template <bool ENV, class NEXT1, class NEXT2>
+ZD LightSample sample_light(const DScene &S, f3 origin, float u_pick, NEXT1 next1, NEXT2 next2) {
     LightSample L;
-    int n = S.light_count;
-    if (n <= 0) {  // the reference would index out of bounds; contribute nothing
+    int n = (ENV ? S.env_count : 0) + S.light_count;
+    if (n <= 0) {  // the reference would index out of bounds; consume the mesh branch's dimensions, contribute nothing
+        (void)next1(); (void)next2();
         L.wi = mk3(0.0f, 0.0f, 1.0f); L.dist = 0.0f; L.pdf = 1.0f; L.eval = mk3(0.0f);
         return L;
     }
     int idx = clampi((int)(u_pick * (float)n), 0, n - 1);
+    if (ENV && idx < S.env_count) {                              // envmap.py:223-238
+        f2 u = next2();
+        int iy, ix; float uy, ux;
+        sample_alias_table(S, S.map_h, u.y, 0, iy, uy);
+        sample_alias_table(S, S.map_w, u.x, S.map_h + iy * S.map_w, ix, ux);
+        f2 uv; uv.x = ((float)ix + ux) * rcp((float)S.map_w); uv.y = ((float)iy + uy) * rcp((float)S.map_h);
+        L.wi = uv_to_direction(uv); L.dist = 1e30f;
+        L.pdf = S.env_pdf[iy * S.map_w + ix] * env_pdf_scale(uv.y, n);
+        L.eval = env_lookup(S, uv);
+        return L;
+    }
+    if (ENV) idx -= S.env_count;
+    float u_prim = next1();
+    f2 u_pt = next2();
     int inst = S.light_insts[idx];
     int b = S.inst_tri_begin[inst];
     int T = S.inst_tri_begin[inst + 1] - b;
@@ -190,11 +250,12 @@ ZD LightSample sample_light(const DScene &S, f3 origin, float u_pick, float u_pr
 }
 
 // sample_light_pdf (light.py:84-111): pdf of having light-sampled point p on (inst, slot)
+template <bool ENV>
 ZD float sample_light_pdf(const DScene &S, f3 origin, int inst, int slot, f3 p) {
     float4 r6 = S.shade[8 * (size_t)slot + 6];
     int T = S.inst_tri_begin[inst + 1] - S.inst_tri_begin[inst];
     f3 wi; float c, d2;
-    return light_pdf(origin, p, xyz(r6), r6.w, S.light_count * T, wi, c, d2);
+    return light_pdf(origin, p, xyz(r6), r6.w, ((ENV ? S.env_count : 0) + S.light_count) * T, wi, c, d2);
 }
 
 ZD float balanced_heuristic(float a, float b) { return a * rcp(fmaxf(a + b, 1e-4f)); }   // prb.py:12-13

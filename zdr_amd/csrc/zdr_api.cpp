@@ -246,6 +246,7 @@ struct zdr_scene {
     float *d_emission = nullptr;
     int32_t *d_light_insts = nullptr, *d_inst_tri_begin = nullptr, *d_slot_of_tri = nullptr;
     uint32_t *d_pmj = nullptr; uint16_t *d_bn = nullptr; SamplerTables tab{};
+    float4 *d_env_tex = nullptr; float *d_alias_prob = nullptr, *d_env_pdf = nullptr; int32_t *d_alias_idx = nullptr;
     float4 *d_partial = nullptr; size_t partial_bytes = 0;
     float *d_cells = nullptr; size_t cells_bytes = 0;       // backward staging cells, (tex_h+1) x (tex_w+1) x 16 floats
     unsigned long long *d_counters = nullptr;
@@ -388,7 +389,7 @@ extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_isect); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
-    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_partial); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
+    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
     delete s;
     return ZDR_OK;
 }
@@ -416,11 +417,36 @@ extern "C" int zdr_scene_set_emissions(zdr_scene *s, const float *inst_emission,
     return ZDR_OK;
 }
 
+extern "C" int zdr_scene_set_envmap(zdr_scene *s, const float *tex, uint32_t tex_h, uint32_t tex_w, const float *alias_prob,
+                                    const int32_t *alias_idx, const float *pdf, uint32_t map_w, uint32_t map_h) {
+    if (!s) return fail(ZDR_E_INVALID, "null scene");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());     // nothing in flight may still read the old tables
+    (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf);
+    s->d_env_tex = nullptr; s->d_alias_prob = nullptr; s->d_alias_idx = nullptr; s->d_env_pdf = nullptr;
+    s->ds.env_count = 0; s->ds.env_tex = nullptr; s->ds.alias_prob = nullptr; s->ds.alias_idx = nullptr; s->ds.env_pdf = nullptr;
+    if (!tex) return ZDR_OK;
+    if (!alias_prob || !alias_idx || !pdf || !tex_h || !tex_w || !map_w || !map_h) return fail(ZDR_E_INVALID, "bad envmap arguments");
+    size_t n_alias = (size_t)map_h + (size_t)map_h * map_w;
+    for (size_t i = 0; i < n_alias; i++) {
+        size_t lim = i < map_h ? map_h : map_w;
+        if (alias_idx[i] < 0 || (size_t)alias_idx[i] >= lim) return fail(ZDR_E_INVALID, "alias index out of range");
+    }
+    HIPCHK(upload(&s->d_env_tex, tex, (size_t)tex_h * tex_w * sizeof(float4), &s->device_bytes));
+    HIPCHK(upload(&s->d_alias_prob, alias_prob, n_alias * sizeof(float), &s->device_bytes));
+    HIPCHK(upload(&s->d_alias_idx, alias_idx, n_alias * sizeof(int32_t), &s->device_bytes));
+    HIPCHK(upload(&s->d_env_pdf, pdf, (size_t)map_w * map_h * sizeof(float), &s->device_bytes));
+    s->ds.env_tex = s->d_env_tex; s->ds.alias_prob = s->d_alias_prob; s->ds.alias_idx = s->d_alias_idx; s->ds.env_pdf = s->d_env_pdf;
+    s->ds.env_h = (int32_t)tex_h; s->ds.env_w = (int32_t)tex_w; s->ds.map_w = (int32_t)map_w; s->ds.map_h = (int32_t)map_h;
+    s->ds.env_count = 1;
+    return ZDR_OK;
+}
+
 extern "C" int zdr_scene_set_pmj02bn_tables(zdr_scene *s, const uint32_t *pmj, uint32_t nsets, uint32_t nsamples,
                                             const uint16_t *bn, uint32_t ntex, uint32_t bnres) {
     if (!s || !pmj || !bn || !nsets || !nsamples || !ntex || !bnres) return fail(ZDR_E_INVALID, "bad table arguments");
     HIPCHK(hipSetDevice(s->device));
-    (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); s->d_pmj = nullptr; s->d_bn = nullptr;
+    (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); s->d_pmj = nullptr; s->d_bn = nullptr;
     HIPCHK(upload(&s->d_pmj, pmj, (size_t)nsets * nsamples * 2 * sizeof(uint32_t), &s->device_bytes));
     HIPCHK(upload(&s->d_bn, bn, (size_t)ntex * bnres * bnres * sizeof(uint16_t), &s->device_bytes));
     s->tab.pmj = s->d_pmj; s->tab.bn = s->d_bn; s->tab.nsets = nsets; s->tab.nsamples = nsamples; s->tab.ntex = ntex; s->tab.bnres = bnres;

@@ -75,7 +75,7 @@ ZD void flush_counters(const KernelIO &io, const Counters &cnt) {
 
 // ------------------------------------------------------------------------------------- path
 // Forward (and the counting variant): flat regeneration loop, one bounce per trip per live lane.
-template <int SK, class A, bool STATS>
+template <int SK, class A, bool STATS, bool ENV>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     const WorkItem w = decode_block(R);
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
         }
         if (__ballot(alive) == 0ull) break;                 // every lane has exhausted its samples
         if (alive) {
-            bool done = path_bounce<SK, A, false, STATS>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt);
+            bool done = path_bounce<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt);
             if (done) {
                 alive = false;
                 if (!any_nan(ps.L)) sum = sum + clamp_radiance(ps.L);   // integrator.py:27-28
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
 #ifndef ZDR_LDS_VERTICES
 #define ZDR_LDS_VERTICES 2
 #endif
-template <int SK, class A>
+template <int SK, class A, bool ENV>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
         if (__ballot(alive) == 0ull) break;
         if (alive) {
             PathVertex pv; bool has_vertex; float term_plfrac = 0.0f;
-            bool done = path_bounce<SK, A, true, false>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt, &term_plfrac);
+            bool done = path_bounce<SK, A, true, false, ENV>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt, &term_plfrac);
             if (has_vertex) {
                 PackedVertex p = pack_vertex(pv, le_grad);
                 if (nrec < lds_vertices) {
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
 }
 
 // ---------------------------------------------------------------------- direct / collocated
-template <int INTEG, int SK, class A, bool BWD, bool STATS>
+template <int INTEG, int SK, class A, bool BWD, bool STATS, bool ENV>
 __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
     __shared__ float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 1];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerC
             COUNT(C_SAMPLES);
             f3 rad;
             if (INTEG == ZDR_COLLOCATED) rad = collocated_sample<A, BWD, STATS>(S, R, io, lds, o, d, le_grad, cnt, guv, grad);
-            else rad = direct_sample<SK, A, BWD, STATS>(S, R, C, io, lds, smp, o, d, le_grad, cnt, guv, grad);
+            else rad = direct_sample<SK, A, BWD, STATS, ENV>(S, R, C, io, lds, smp, o, d, le_grad, cnt, guv, grad);
             if (!any_nan(rad)) sum = sum + clamp_radiance(rad); else COUNT(C_NAN);
         }
         if (BWD) scatter_push(q, io.cells, w.valid && any_nonzero4(grad) && !any_nan4(grad), guv, grad, R.tex_h, R.tex_w, R.debug_no_scatter);
@@ -297,15 +297,28 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 // ----------------------------------------------------------------------------------- launch
 template <int SK, class A>
 static void launch_path(dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
-    if (backward) hipLaunchKernelGGL((k_path_bwd<SK, A>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-    else if (stats) hipLaunchKernelGGL((k_path<SK, A, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-    else hipLaunchKernelGGL((k_path<SK, A, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    // the environment-light code is a separate instantiation: inside the default kernels it cost 16 % (cbox forward)
+    if (S.env_count > 0) {
+        if (backward) hipLaunchKernelGGL((k_path_bwd<SK, A, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+        else if (stats) hipLaunchKernelGGL((k_path<SK, A, true, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+        else hipLaunchKernelGGL((k_path<SK, A, false, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    } else {
+        if (backward) hipLaunchKernelGGL((k_path_bwd<SK, A, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+        else if (stats) hipLaunchKernelGGL((k_path<SK, A, true, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+        else hipLaunchKernelGGL((k_path<SK, A, false, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    }
 }
 template <int INTEG, int SK, class A>
 static void launch_simple(dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
-    if (backward) hipLaunchKernelGGL((k_simple<INTEG, SK, A, true, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-    else if (stats) hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-    else hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    if (INTEG == ZDR_DIRECT && S.env_count > 0) {
+        if (backward) hipLaunchKernelGGL((k_simple<INTEG, SK, A, true, false, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+        else if (stats) hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, true, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+        else hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, false, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    } else {
+        if (backward) hipLaunchKernelGGL((k_simple<INTEG, SK, A, true, false, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+        else if (stats) hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, true, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+        else hipLaunchKernelGGL((k_simple<INTEG, SK, A, false, false, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
+    }
 }
 template <int SK, class A>
 static void launch_integ(int integrator, dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {

@@ -88,8 +88,27 @@ class Scene:
         self.light_count = int((e > 0).any(axis=1).sum())
         N.check(N.lib().zdr_scene_set_emissions(self._handle, e.ctypes.data, self._stream()))
 
-    def add_envmap(self, filename, compensate_mis=True):
-        raise NotImplementedError("environment lighting (envmap.py) is outside the hot path built so far (SURVEY §8f-3)")
+    def add_envmap(self, image, compensate_mis=True):
+        """Adds a lat-long environment light (render.py:150-156, envmap.py:116-203).  ``image`` is an
+        (H, W, 3|4) float array / tensor (2:1 or 1:1) or the path of a ``.npy`` file holding one — the
+        reference reads an EXR through imageio, which this image does not ship.  ``None`` removes it."""
+        from . import envmap as E
+        if image is None:
+            N.check(N.lib().zdr_scene_set_envmap(self._handle, None, 0, 0, None, None, None, 0, 0))
+            self.env_count = 0
+            return
+        if isinstance(image, str):
+            if not image.endswith(".npy"):
+                raise NotImplementedError("only .npy environment maps can be read here (no EXR reader in this environment); pass an array instead")
+            image = np.load(image)
+        if isinstance(image, torch.Tensor):
+            image = image.detach().cpu().numpy()
+        img = E.prepare_image(image)
+        prob, alias, pdf = E.build_tables(img, compensate_mis=compensate_mis)
+        N.check(N.lib().zdr_scene_set_envmap(self._handle, img.ctypes.data, img.shape[0], img.shape[1], prob.ctypes.data, alias.ctypes.data,
+                                             pdf.ctypes.data, E.SAMPLE_MAP_W, E.SAMPLE_MAP_H))
+        self.env_count = 1
+        self._envmap = (img, prob, alias, pdf)        # kept for tests / the oracle
 
     def set_pmj02bn_tables(self, pmj_samples, blue_noise):
         """pmj_samples: uint32 [nsets][nsamples][2]; blue_noise: uint16 [ntex][res][res] (pmj02bn.py:9-18)."""

@@ -41,10 +41,14 @@ def test_pmj02bn_draws_bit_exact_with_synthetic_tables():
                 assert (got[k, :exp.shape[0]].view(np.uint32) == exp.view(np.uint32)).all(), (spp, seed, q[k])
 
 
-def test_pmj02bn_without_tables_fails_loudly():
-    from zdr_amd._native import ZdrError
+def test_pmj02bn_without_tables_fails_loudly_at_the_c_abi():
+    # the Python Scene generates tables on demand; the C-ABI itself refuses to render without any
+    import ctypes as C
+    from zdr_amd import _native as N
     scene = make_scene("path")
-    scene.sampler = "pmj02bn"
     m = torch.rand((8, 8, 4), device="cuda")
-    with pytest.raises(ZdrError, match="tables"):
-        scene.render(m, res=(16, 16), spp=4)
+    p = scene._params((16, 16), 4, 0, (8, 8))
+    p.sampler = N.SAMPLER_PMJ02BN
+    img = torch.zeros((16, 16, 4), device="cuda")
+    rc = N.lib().zdr_render_forward(scene._handle, C.byref(p), m.data_ptr(), img.data_ptr(), None)
+    assert rc == -3 and b"tables" in N.lib().zdr_last_error()

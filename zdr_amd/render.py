@@ -116,12 +116,17 @@ class Scene:
         bn = np.ascontiguousarray(blue_noise, np.uint16)
         assert pmj.ndim == 3 and pmj.shape[2] == 2 and bn.ndim == 3 and bn.shape[1] == bn.shape[2]
         N.check(N.lib().zdr_scene_set_pmj02bn_tables(self._handle, pmj.ctypes.data, pmj.shape[0], pmj.shape[1], bn.ctypes.data, bn.shape[0], bn.shape[1]))
+        self._pmj_tables_set = True
 
     # ------------------------------------------------------------------------- launching
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _params(self, res, spp, seed, tex_hw, rect=None, samples=None, camera=None, integrator=None) -> N.RenderParams:
+        if self.sampler == "pmj02bn" and not getattr(self, "_pmj_tables_set", False):
+            # the reference's pbrt tables are not shipped: fall back to generated ones (zdr_amd/pmj02bn_tables.py)
+            from . import pmj02bn_tables
+            self.set_pmj02bn_tables(*pmj02bn_tables.default_tables(verbose=True))
         p = N.RenderParams()
         p.integrator, p.sampler = self._integrator if integrator is None else integrator, N.SAMPLERS[self.sampler]
         p.width, p.height = int(res[0]), int(res[1])

@@ -25,17 +25,20 @@ ZD float4 f4(v4f a) { return make_float4(a.x, a.y, a.z, a.w); }
 // Plane-form ray/triangle test (Havel & Herout style).  isect[3 slot + {0,1,2}] = N {n, n.p0},
 // U {nu, du}, V {nv, dv}, precomputed in float64 on the host (zdr_api.cpp):
 //   t = (N.w - n.o) / (n.d),  p = o + t d,  u = nu.p + du,  v = nv.p + dv,  hit: tmin < t < tmax, u, v >= 0, u + v <= 1
-// 26 VALU per triangle against 46 for Moeller-Trumbore with precomputed edges; the closest-hit loops
+// 24 VALU per triangle against 46 for Moeller-Trumbore with precomputed edges; the closest-hit loops
 // track only (t, slot) and evaluate the barycentrics of the winner once, after the loop.
+// The operation order (explicit fmaf) is the one of the packed pair test below, so that the BVH
+// leaves and the brute-force loop decide every ray identically.
 ZD bool tri_test(float4 N, float4 U, float4 V, f3 o, f3 d, float tmin, float tmax, float &t) {
-    float nd = N.x * d.x + N.y * d.y + N.z * d.z;
-    float tn = N.w - (N.x * o.x + N.y * o.y + N.z * o.z);
-    float tt = tn * rcp(nd);
-    f3 p = o + d * tt;
-    float uu = U.x * p.x + U.y * p.y + U.z * p.z + U.w;
-    float vv = V.x * p.x + V.y * p.y + V.z * p.z + V.w;
+    float nd = fmaf(N.z, d.z, fmaf(N.y, d.y, N.x * d.x));
+    float no = fmaf(N.z, o.z, fmaf(N.y, o.y, N.x * o.x));
+    float tt = (N.w - no) * rcp(nd);
+    float px = fmaf(d.x, tt, o.x), py = fmaf(d.y, tt, o.y), pz = fmaf(d.z, tt, o.z);
+    float uu = fmaf(U.z, pz, fmaf(U.y, py, U.x * px)) + U.w;
+    float vv = fmaf(V.z, pz, fmaf(V.y, py, V.x * px)) + V.w;
+    float c = fminf(fminf(uu, vv), 1.0f - (uu + vv));
     t = tt;
-    return (tt > tmin) & (tt < tmax) & (uu >= 0.0f) & (vv >= 0.0f) & (uu + vv <= 1.0f);
+    return (tt > tmin) & (tt < tmax) & (c >= 0.0f);
 }
 
 ZD void hit_barycentrics(const DScene &S, Hit &h, f3 o, f3 d) {
@@ -46,27 +49,61 @@ ZD void hit_barycentrics(const DScene &S, Hit &h, f3 o, f3 d) {
     h.v = V.x * p.x + V.y * p.y + V.z * p.z + V.w;
 }
 
+// ---- packed pair test -------------------------------------------------------------------------
+// On gfx950 an fp32 VALU instruction occupies its SIMD for 4 cycles per wave64 whether it is v_fma_f32
+// or v_pk_fma_f32 (profiles/r1_valu_issue_rate.txt): the packed forms do two floats per lane for the
+// price of one.  The brute-force loops therefore test TWO triangles per trip, one in each half of a
+// float2: S.pairs holds, per pair of slots (2k, 2k+1), six float4
+//   {Nx Nx' Ny Ny'} {Nz Nz' Nw Nw'} {Ux Ux' Uy Uy'} {Uz Uz' Uw Uw'} {Vx Vx' Vy Vy'} {Vz Vz' Vw Vw'}
+// (the plane-form records of isect, interleaved).  They are wave-uniform and arrive as SGPR pairs,
+// the ray is broadcast to both halves through op_sel.  An odd triangle count is padded with an
+// all-zero record (0 * inf = NaN fails every comparison).
+typedef float v2f __attribute__((ext_vector_type(2)));
+ZD v2f splat(float a) { v2f r = {a, a}; return r; }
+ZD v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+struct PairHit { v2f t, c; };   // c >= 0 <=> barycentrics inside; t = ray parameter
+ZD PairHit pair_test(const_v4f_ptr q, f3 o, f3 d) {
+    v4f q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+    v2f dx = splat(d.x), dy = splat(d.y), dz = splat(d.z), ox = splat(o.x), oy = splat(o.y), oz = splat(o.z);
+    v2f nd = pfma(q1.xy, dz, pfma(q0.zw, dy, q0.xy * dx));
+    v2f no = pfma(q1.xy, oz, pfma(q0.zw, oy, q0.xy * ox));
+    v2f tn = q1.zw - no;
+    v2f r = {rcp(nd.x), rcp(nd.y)};
+    PairHit h;
+    h.t = tn * r;
+    v2f px = pfma(dx, h.t, ox), py = pfma(dy, h.t, oy), pz = pfma(dz, h.t, oz);
+    v2f uu = pfma(q3.xy, pz, pfma(q2.zw, py, q2.xy * px)) + q3.zw;
+    v2f vv = pfma(q5.xy, pz, pfma(q4.zw, py, q4.xy * px)) + q5.zw;
+    v2f m = splat(1.0f) - (uu + vv);
+    h.c.x = fminf(fminf(uu.x, vv.x), m.x);   // v_min3_f32; a NaN here implies a NaN or infinite t, which the range test rejects
+    h.c.y = fminf(fminf(uu.y, vv.y), m.y);
+    return h;
+}
+
 struct BruteAccel {
     static constexpr bool kNeedsLds = false;
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
-        const_v4f_ptr tri = as_constant(S.isect);
-#pragma unroll ZDR_TRI_UNROLL
-        for (int s = 0; s < S.ntris; s++) {
-            float t;
-            bool ok = tri_test(f4(tri[3 * s]), f4(tri[3 * s + 1]), f4(tri[3 * s + 2]), o, d, tmin, h.t, t);
-            h.t = ok ? t : h.t; h.slot = ok ? s : h.slot;
+        const_v4f_ptr q = as_constant(S.pairs);
+#pragma unroll 1
+        for (int s = 0; s < S.ntris; s += 2, q += 6) {
+            PairHit ph = pair_test(q, o, d);
+            bool ok = (ph.t.x > tmin) & (ph.t.x < h.t) & (ph.c.x >= 0.0f);
+            h.t = ok ? ph.t.x : h.t; h.slot = ok ? s : h.slot;
+            ok = (ph.t.y > tmin) & (ph.t.y < h.t) & (ph.c.y >= 0.0f);
+            h.t = ok ? ph.t.y : h.t; h.slot = ok ? s + 1 : h.slot;
         }
         hit_barycentrics(S, h, o, d);
         return h;
     }
     ZD static bool any(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         bool occ = false;
-        const_v4f_ptr tri = as_constant(S.isect);
-#pragma unroll ZDR_TRI_UNROLL
-        for (int s = 0; s < S.ntris; s++) {
-            float t;
-            occ |= tri_test(f4(tri[3 * s]), f4(tri[3 * s + 1]), f4(tri[3 * s + 2]), o, d, tmin, tmax, t);
+        const_v4f_ptr q = as_constant(S.pairs);
+#pragma unroll 1
+        for (int s = 0; s < S.ntris; s += 2, q += 6) {
+            PairHit ph = pair_test(q, o, d);
+            occ |= ((ph.t.x > tmin) & (ph.t.x < tmax) & (ph.c.x >= 0.0f)) | ((ph.t.y > tmin) & (ph.t.y < tmax) & (ph.c.y >= 0.0f));
         }
         return occ;
     }

@@ -18,6 +18,7 @@
 //   an unused child has an inverted box.
 struct DScene {
     const float4 *isect;
+    const float4 *pairs;            // brute-force accel only: isect records of slots (2k, 2k+1) interleaved, 6 float4 per pair (accel.h)
     const float4 *shade;
     const float4 *nodes;
     const float *emission;          // ninst x 3   (heap slot 23333)

@@ -242,7 +242,7 @@ struct zdr_scene {
     uint32_t bvh_nodes = 0, bvh_depth = 0, stack_entries = 8;
     std::vector<int32_t> inst_tri_begin;
     std::vector<float> emission;
-    float4 *d_isect = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
+    float4 *d_isect = nullptr, *d_pairs = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
     float *d_emission = nullptr;
     int32_t *d_light_insts = nullptr, *d_inst_tri_begin = nullptr, *d_slot_of_tri = nullptr;
     uint32_t *d_pmj = nullptr; uint16_t *d_bn = nullptr; SamplerTables tab{};
@@ -348,6 +348,17 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     hipError_t e = hipSuccess;
     auto up = [&](auto **dst, const void *src, size_t bytes) { if (e == hipSuccess) e = upload(dst, src, bytes, &s->device_bytes); };
     up(&s->d_isect, isect.data(), isect.size() * sizeof(float4));
+    if (!use_bvh) {
+        // brute-force loops test two slots per trip with packed fp32 math: interleave the records
+        size_t npairs = ((size_t)ntris + 1) / 2;
+        std::vector<float> pr(24 * npairs, 0.0f);
+        for (uint32_t slot = 0; slot < ntris; slot++) {
+            const float *src = (const float *)&isect[3 * (size_t)slot];
+            float *dst = &pr[24 * (size_t)(slot / 2) + (slot & 1)];
+            for (int k = 0; k < 12; k++) dst[2 * k] = src[k];
+        }
+        up(&s->d_pairs, pr.data(), pr.size() * sizeof(float));
+    }
     up(&s->d_shade, shade.data(), shade.size() * sizeof(float4));
     up(&s->d_nodes, nodes.data(), nodes.size() * sizeof(float4));
     up(&s->d_emission, s->emission.data(), s->emission.size() * sizeof(float));
@@ -356,7 +367,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     up(&s->d_slot_of_tri, slot_of_tri.data(), slot_of_tri.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long));
     if (e != hipSuccess) { std::string m = hipGetErrorString(e); zdr_scene_destroy(s); return fail(ZDR_E_HIP, "scene upload: " + m); }
-    s->ds.isect = s->d_isect; s->ds.shade = s->d_shade; s->ds.nodes = s->d_nodes; s->ds.emission = s->d_emission;
+    s->ds.isect = s->d_isect; s->ds.pairs = s->d_pairs; s->ds.shade = s->d_shade; s->ds.nodes = s->d_nodes; s->ds.emission = s->d_emission;
     s->ds.light_insts = s->d_light_insts; s->ds.inst_tri_begin = s->d_inst_tri_begin; s->ds.slot_of_tri = s->d_slot_of_tri;
     s->ds.ntris = (int32_t)ntris; s->ds.ninst = (int32_t)ninst; s->ds.light_count = light_count; s->ds.nnodes = (int32_t)s->bvh_nodes; s->ds.stack_entries = (int32_t)s->stack_entries;
     *out = s;
@@ -388,7 +399,7 @@ extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int a
 extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
-    (void)hipFree(s->d_isect); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
+    (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
     (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
     delete s;
     return ZDR_OK;

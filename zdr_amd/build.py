@@ -50,7 +50,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         # pairs: measured 23.9 -> 17.7 ms on the cbox forward pass (profiles/r1_ab_flags.txt).
         ("zdr_kernels.hip", ["-O3", "-munsafe-fp-atomics", "-fno-slp-vectorize", *os.environ.get("ZDR_KERNEL_FLAGS", "").split()]),
         # host side: IEEE float32 for the per-triangle constants
-        ("zdr_api.cpp", ["-O2", "-ffp-contract=off", "-x", "hip"]),
+        # (-D options of ZDR_KERNEL_FLAGS go to both halves: some macros size shared workspaces)
+        ("zdr_api.cpp", ["-O2", "-ffp-contract=off", "-x", "hip", *[f for f in os.environ.get("ZDR_KERNEL_FLAGS", "").split() if f.startswith("-D")]]),
     ]
     procs = []
     for src, extra in jobs:

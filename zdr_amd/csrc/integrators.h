@@ -1,7 +1,7 @@
 // integrators.h — the three radiance estimators of the reference and their adjoints, written
 // for wave64: one lane owns one pixel and walks its samples in index order (the summation order
 // of integrator.py:15-29), but the path integrator runs as a flat state machine — each loop
-// trip every live lane advances its path by ONE bounce and finished lanes immediately start
+// trip every live lane shades ONE vertex of its path and finished lanes immediately start
 // their next sample, so short paths do not idle behind the longest path of the wave.
 #pragma once
 #include "accel.h"
@@ -192,15 +192,15 @@ struct PathState {
     Sampler smp;
 };
 
-// Advance one live path by one bounce (prb.py:23-87 is the body of `for depth in range(max_depth)`).
-// Returns true when the path has terminated.  BWD: fills pv and sets has_vertex when a vertex was
-// shaded, and sets term_Li when the path ended on an emitter.
-template <int SK, class A, bool BWD, bool STATS, bool ENV>
-ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                    PathState &ps, PathVertex &pv, bool &has_vertex, f3 &term_Li, Counters &cnt, float *term_plfrac = nullptr) {
-    has_vertex = false;
-    COUNT(C_CLOSEST);
-    Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+// One bounce of prb.py:23-87 (`for depth in range(max_depth)`) in two halves, so that the kernels can
+// order a trip as  shade vertex -> shadow ray -> sample -> trace -> classify  and every live lane
+// enters a trip with a vertex to shade (zdr_kernels.hip).
+//
+// path_arrive: what the ray (ps.o, ps.d) reached (prb.py:25-46).  Returns true when the path ends here
+// (miss, back face, emitter, untextured instance); otherwise `it` is the vertex to shade.  BWD: sets
+// term_Li (and the MIS-weight fraction of the terminal emitter) when the path ended on a light.
+template <bool BWD, bool STATS, bool ENV>
+ZD bool path_arrive(const DScene &S, PathState &ps, const Hit &h, Interaction &it, f3 &term_Li, Counters &cnt, float *term_plfrac = nullptr) {
     if (h.slot < 0) {                                                             // prb.py:26-32, in the form of direct.py:70-83
         if (ENV && S.env_count > 0) {
             f3 em = env_lookup(S, direction_to_uv(ps.d));
@@ -213,7 +213,7 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
         return true;
     }
     COUNT(C_HITS);
-    Interaction it = surface_interact(S, h);
+    it = surface_interact(S, h);
     if (dot(-ps.d, it.ng) < 1e-4f || dot(-ps.d, it.ns) < 1e-4f) return true;      // prb.py:35-36
     f3 em = ld3(S.emission + 3 * it.inst);
     if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {                              // prb.py:39-44
@@ -226,11 +226,19 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
         return true;
     }
     if (it.inst > 0) return true;                                                 // prb.py:45-46
+    return false;
+}
+
+// path_shade: next-event estimation, BSDF sampling and Russian roulette at the vertex `it`
+// (prb.py:47-87).  Returns true when the path stops here; otherwise (ps.o, ps.d) is the next ray.
+// BWD: fills pv, the record of this vertex.
+template <int SK, class A, bool BWD, bool STATS, bool ENV>
+ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
+                   PathState &ps, const Interaction &it, PathVertex &pv, Counters &cnt) {
     float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
     f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
     COUNT(C_SHADED);
     if (BWD) {
-        has_vertex = true;
         pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
         pv.T = mk3(0.0f); pv.fLW = mk3(0.0f); pv.bnorm = mk3(0.0f); pv.neeM = mk3(0.0f); pv.dlnp = 0.0f; pv.rr = 0;
     }
@@ -298,6 +306,93 @@ ZD bool path_bounce(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     ps.depth++;
     if (ps.depth >= R.max_depth) stop = true;
     return stop;
+}
+
+// ---- primary queue -----------------------------------------------------------------------------
+// Camera rays are generated and traced in BATCHES by the whole wave — one sample index for all 64
+// pixels of the tile per step, every lane busy — classified, and the vertices worth shading are parked
+// in a wave-wide FIFO in global memory.  Whenever a lane's path ends it takes the next parked vertex,
+// WHATEVER pixel it belongs to: lanes do not own pixels in the flat loop, so no lane idles because
+// "its" pixel happened to have short paths (with one pixel per lane a wave ran until its slowest lane
+// had finished, 25 % of all trips on cbox), and a path of k shaded vertices costs k trips, not k + 1.
+// Entry e of block b: two float4 at queue[(b * CAP * 64 + e % (CAP * 64)) * 2 + {0, 1}]
+//   {d.xyz, u} {v, bits(slot), bits(sampler LCG state), bits(pixel-in-tile << 26 | sample index)}
+// Pushes and pops are compacted with ballot/mbcnt, so both sides touch consecutive entries.
+struct PrimaryQueue { float4 *base; uint32_t head, tail; };    // head, tail: wave-uniform entry counters
+#define ZDR_QUEUE_ENTRIES (ZDR_RING_CAP * 64)
+static_assert(ZDR_RING_BATCH * 64 + 64 <= ZDR_QUEUE_ENTRIES, "a refill must fit behind a queue that could not serve every idle lane");
+
+ZD PrimaryQueue queue_init(const KernelIO &io) {
+    PrimaryQueue r; r.base = io.ring + (size_t)blockIdx.x * (ZDR_QUEUE_ENTRIES * 2); r.head = 0; r.tail = 0;
+    return r;
+}
+ZD uint32_t lane_rank(unsigned long long mask) {               // number of set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Generates ZDR_RING_BATCH camera samples for every pixel of the tile (lane = pixel here).  Samples that end
+// at the camera ray (miss, emitter, back face) are finished at once: their radiance goes to `sum`,
+// this lane's own pixel.
+template <int SK, class A, bool BWD, bool STATS, bool ENV>
+ZD void primary_refill(const DScene &S, const RenderCfg &R, const SamplerCfg &C, int *lds, int x, int y, bool valid,
+                       uint32_t perm_seed, uint32_t &next_sample, uint32_t s_end, PrimaryQueue &q, f3 &sum, Counters &cnt) {
+    for (int b = 0; b < ZDR_RING_BATCH && next_sample < s_end; b++, next_sample++) {   // wave-uniform
+        bool park = false;
+        float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0;
+        if (valid) {
+            PathState ps;
+            ps.smp = sampler_make<SK>(C, (uint32_t)x, (uint32_t)y, perm_seed, next_sample);
+            pixel_ray<SK>(R, C, ps.smp, x, y, ps.o, ps.d);
+            ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;   // prb.py:20-22
+            COUNT(C_SAMPLES); COUNT(C_CLOSEST);
+            Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+            Interaction it; f3 tl;
+            if (path_arrive<false, STATS, ENV>(S, ps, h, it, tl, cnt)) {
+                if (!BWD) {                                                     // a path without vertices has no gradient
+                    if (!any_nan(ps.L)) sum = sum + clamp_radiance(ps.L);       // integrator.py:27-28
+                    else COUNT(C_NAN);
+                }
+            } else {
+                park = true;
+                e0 = make_float4(ps.d.x, ps.d.y, ps.d.z, h.u);
+                e1 = make_float4(h.v, __int_as_float(h.slot), __uint_as_float(ps.smp.state), __uint_as_float(((uint32_t)threadIdx.x << 26) | next_sample));
+            }
+        }
+        const unsigned long long m = __ballot(park);
+        if (park) {
+            float4 *e = q.base + (size_t)((q.tail + lane_rank(m)) % ZDR_QUEUE_ENTRIES) * 2;
+            e[0] = e0; e[1] = e1;
+        }
+        q.tail += (uint32_t)__popcll(m);
+    }
+}
+
+// An idle lane takes the oldest parked vertex that no lower idle lane takes: the path state as it is right
+// after the camera ray.  Returns the pixel (lane index within the tile) the path belongs to, or -1.
+template <int SK>
+ZD int primary_pop(const DScene &S, const SamplerCfg &C, bool idle, const uint32_t *lds_perm_seed, int tile_x0, int tile_y0,
+                   PrimaryQueue &q, PathState &ps, Interaction &it) {
+    const unsigned long long m = __ballot(idle);
+    const uint32_t avail = q.tail - q.head, rank = lane_rank(m), want = (uint32_t)__popcll(m);
+    const bool take = idle && rank < avail;
+    int pix = -1;
+    if (take) {
+        const float4 *e = q.base + (size_t)((q.head + rank) % ZDR_QUEUE_ENTRIES) * 2;
+        float4 a = e[0], b = e[1];
+        Hit h; h.slot = __float_as_int(b.y); h.u = a.w; h.v = b.x; h.t = 0.0f;
+        it = surface_interact(S, h);
+        ps.d = mk3(a.x, a.y, a.z); ps.o = mk3(0.0f);
+        ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
+        const uint32_t key = __float_as_uint(b.w);
+        pix = (int)(key >> 26);
+        ps.smp.px = (uint32_t)(tile_x0 + (pix & 7)); ps.smp.py = (uint32_t)(tile_y0 + (pix >> 3));
+        ps.smp.sample_index = key & 0x03ffffffu;
+        ps.smp.dimension = 2;                                                   // pixel_ray drew one 2-D sample
+        ps.smp.permutation_seed = lds_perm_seed[pix];
+        ps.smp.state = __float_as_uint(b.z);
+    }
+    q.head += (want < avail) ? want : avail;
+    return pix;
 }
 
 // The vertex as the sweep stores it: four float4 (+ a fifth for vertices at depth >= rr_depth).  The NEE

@@ -7,6 +7,14 @@
 
 #define ZDR_MAX_RECORDED_DEPTH 16     // prb.py:15 max_depth; vertex records kept per path in backward
 
+// primary ring (integrators.h): parked camera-ray vertices per lane, and camera samples generated per refill
+#ifndef ZDR_RING_CAP
+#define ZDR_RING_CAP 32
+#endif
+#ifndef ZDR_RING_BATCH
+#define ZDR_RING_BATCH 8
+#endif
+
 // Wave-uniform launch configuration (kernel argument, lives in SGPRs).
 struct RenderCfg {
     int32_t width, height;
@@ -31,6 +39,7 @@ struct KernelIO {
     float *d_material;                // backward: += gathered from the staging cells by k_cells_to_grad
     float *cells;                     // backward: (tex_h + 1) x (tex_w + 1) staging cells of 16 floats, zeroed per call
     unsigned long long *counters;     // stats variant: 8 counters
+    float4 *ring;                     // path integrator: per-block rings of parked camera-ray vertices (integrators.h)
 };
 
 int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,

@@ -248,6 +248,7 @@ struct zdr_scene {
     uint32_t *d_pmj = nullptr; uint16_t *d_bn = nullptr; SamplerTables tab{};
     float4 *d_env_tex = nullptr; float *d_alias_prob = nullptr, *d_env_pdf = nullptr; int32_t *d_alias_idx = nullptr;
     float4 *d_partial = nullptr; size_t partial_bytes = 0;
+    float4 *d_ring = nullptr; size_t ring_bytes = 0;     // primary rings of the path kernels (integrators.h)
     float *d_cells = nullptr; size_t cells_bytes = 0;       // backward staging cells, (tex_h+1) x (tex_w+1) x 16 floats
     unsigned long long *d_counters = nullptr;
     uint64_t device_bytes = 0;
@@ -400,7 +401,7 @@ extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
-    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
+    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
     delete s;
     return ZDR_OK;
 }
@@ -548,6 +549,19 @@ static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
     return ZDR_OK;
 }
 
+// One FIFO of ZDR_RING_CAP x 64 parked camera-ray vertices per block of the launch
+// (two float4 each): 64 KiB per block, about 1 GiB at the default 16384 blocks, whatever the spp.
+static int ensure_ring(zdr_scene *s, const RenderCfg &R) {
+    size_t nblocks = (((size_t)R.tiles_x * R.tiles_y * R.nchunks + 7) >> 3) << 3;
+    size_t need = nblocks * ZDR_RING_CAP * 2 * 64 * sizeof(float4);
+    if (need > s->ring_bytes) {
+        (void)hipFree(s->d_ring); s->d_ring = nullptr; s->ring_bytes = 0;
+        HIPCHK(hipMalloc((void **)&s->d_ring, need));
+        s->ring_bytes = need;
+    }
+    return ZDR_OK;
+}
+
 static int ensure_cells(zdr_scene *s, const RenderCfg &R, hipStream_t st) {
     size_t need = (size_t)(R.tex_h + 1) * (R.tex_w + 1) * 16 * sizeof(float);
     if (need > s->cells_bytes) {
@@ -568,7 +582,12 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     rc = make_sampler_cfg(s, p->sampler, p->seed, p->spp, C); if (rc) return rc;
     if (backward) { rc = ensure_cells(s, R, (hipStream_t)stream); if (rc) return rc; }
     else if (!stats) { rc = ensure_partial(s, R); if (rc) return rc; }
+    if (p->integrator == ZDR_PATH) {
+        if (p->spp > (1u << 26)) return fail(ZDR_E_UNSUPPORTED, "path integrator: spp above 2^26");   // queue entries pack pixel << 26 | sample
+        rc = ensure_ring(s, R); if (rc) return rc;
+    }
     KernelIO io; memset(&io, 0, sizeof io);
+    io.ring = s->d_ring;
     io.material = (const float4 *)material; io.image = (float4 *)image; io.partial = s->d_partial;
     io.d_image = (const float4 *)d_image; io.d_material = d_material; io.cells = s->d_cells; io.counters = s->d_counters;
     // every pointer a kernel variant dereferences must be live before anything is launched
@@ -576,6 +595,7 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (!backward && !stats && !io.image) return fail(ZDR_E_INVALID, "forward needs an image");
     if (!backward && !stats && R.nchunks > 1 && !io.partial) return fail(ZDR_E_NOMEM, "chunk workspace missing");
     if (stats && !io.counters) return fail(ZDR_E_NOMEM, "counter buffer missing");
+    if (p->integrator == ZDR_PATH && !io.ring) return fail(ZDR_E_NOMEM, "primary ring workspace missing");
     if (stats && p->integrator == ZDR_UVGRAD) return fail(ZDR_E_UNSUPPORTED, "no statistics for render_duvdxy");
     if (zdr_launch_render(s->ds, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
         return fail(ZDR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(hipGetLastError()));

@@ -74,46 +74,69 @@ ZD void flush_counters(const KernelIO &io, const Counters &cnt) {
 }
 
 // ------------------------------------------------------------------------------------- path
-// Forward (and the counting variant): flat regeneration loop, one bounce per trip per live lane.
+// Forward (and the counting variant).  Two alternating phases per wave:
+//   refill  lane = pixel: ZDR_RING_BATCH camera samples per pixel are generated, traced and classified by the
+//           whole wave and the vertices to shade are parked in the wave's FIFO (integrators.h);
+//   flat loop  a lane is just a worker: it takes the next parked vertex (of ANY pixel of the tile) and
+//           each trip shades one vertex:  shade -> shadow ray -> BSDF sample -> trace -> classify.
+// Radiance of a finished path goes to its pixel's accumulator in LDS (ds_add_f32; one wave, program
+// order, so the sum is reproducible).
 template <int SK, class A, bool STATS, bool ENV>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
+    __shared__ uint32_t lds_perm[WAVE];
+    __shared__ float lds_sum[3 * WAVE];
+    const int lane = threadIdx.x;
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
+    lds_perm[lane] = perm_seed;
+    lds_sum[lane] = 0.0f; lds_sum[lane + WAVE] = 0.0f; lds_sum[lane + 2 * WAVE] = 0.0f;
+    __syncthreads();
     Counters cnt;
 #pragma unroll
     for (int i = 0; i < 8; i++) cnt.c[i] = 0;
-    PathVertex pv; bool has_vertex; f3 term_Li = mk3(0.0f);
-    f3 sum = mk3(0.0f);
-    uint32_t it = w.s_begin;
-    bool alive = false;
-    PathState ps;
+    PathVertex pv; f3 term_Li = mk3(0.0f);
+    f3 sum = mk3(0.0f);                                     // paths of this lane's pixel that ended at the camera ray
+    uint32_t next_sample = (__ballot(w.valid) != 0ull) ? w.s_begin : w.s_end;
+    PrimaryQueue q = queue_init(io);
+    bool alive = false; int pix = 0;
+    PathState ps; Interaction it;
     ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
     ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
+    it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
     for (;;) {
-        if (!alive && w.valid && it < w.s_end) {            // regenerate: next sample of this pixel
-            ps.smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
-            pixel_ray<SK>(R, C, ps.smp, w.x, w.y, ps.o, ps.d);
-            ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;   // prb.py:20-22
-            alive = true; it++;
-            COUNT(C_SAMPLES);
+        if (q.tail - q.head < (uint32_t)__popcll(__ballot(!alive)) && next_sample < w.s_end)
+            primary_refill<SK, A, false, STATS, ENV>(S, R, C, lds, w.x, w.y, w.valid, perm_seed, next_sample, w.s_end, q, sum, cnt);
+        const int took = primary_pop<SK>(S, C, !alive, lds_perm, w.x - (lane & 7), w.y - (lane >> 3), q, ps, it);
+        if (took >= 0) { alive = true; pix = took; }
+        if (__ballot(alive) == 0ull) {
+            if (next_sample >= w.s_end) break;              // queue empty (idle lanes would have popped), nothing left to generate
+            continue;                                       // every sample of the batch ended at the camera ray
         }
-        if (__ballot(alive) == 0ull) break;                 // every lane has exhausted its samples
         if (alive) {
-            bool done = path_bounce<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt);
+            bool done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, cnt);
+            if (!done) {
+                COUNT(C_CLOSEST);
+                Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+                done = path_arrive<false, STATS, ENV>(S, ps, h, it, term_Li, cnt);
+            }
             if (done) {
                 alive = false;
-                if (!any_nan(ps.L)) sum = sum + clamp_radiance(ps.L);   // integrator.py:27-28
-                else COUNT(C_NAN);
+                if (!any_nan(ps.L)) {                       // integrator.py:27-28
+                    f3 c = clamp_radiance(ps.L);
+                    atomicAdd(&lds_sum[pix], c.x); atomicAdd(&lds_sum[pix + WAVE], c.y); atomicAdd(&lds_sum[pix + 2 * WAVE], c.z);
+                } else COUNT(C_NAN);
             }
         }
     }
+    __syncthreads();
+    sum = sum + mk3(lds_sum[lane], lds_sum[lane + WAVE], lds_sum[lane + 2 * WAVE]);
     if (!STATS) store_pixel(R, C, io, w, sum);              // the stats variant owns no image
     flush_counters<STATS>(io, cnt);
 }
 
-// PRB backward with ONE traversal.  Each trip a live lane advances its path by one bounce and
-// appends the shaded vertex to its record list: vertices before the first Russian-roulette depth (at
+// PRB backward with ONE traversal.  Each trip a live lane shades one vertex of its path (same trip
+// order, primary queue and pixel-free lanes as k_path) and appends it to its record list: vertices before the first Russian-roulette depth (at
 // most ZDR_LDS_VERTICES of them) live in LDS laid out [slot][float4][lane] (conflict-free ds_*_b128,
 // 4 float4 + one float), deeper ones (25 % of all vertices on cbox) in per-lane scratch (5 float4).
 // When a path ends, a short wave-uniform loop sweeps its records last to first and queues the
@@ -134,31 +157,43 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     Counters cnt;
-    const f3 le_grad = load_le_grad(C, io, w);
+    __shared__ uint32_t lds_perm[WAVE];
+    __shared__ float lds_leg[3 * WAVE];
+    f3 le_grad = load_le_grad(C, io, w);                    // of this lane's pixel; a popped path brings its own pixel's
+    lds_perm[lane] = perm_seed;
+    lds_leg[lane] = le_grad.x; lds_leg[lane + WAVE] = le_grad.y; lds_leg[lane + 2 * WAVE] = le_grad.z;
+    __syncthreads();
     ScatterQueue q = scatter_queue_init(lds_q);
     PackedVertex deep[ZDR_MAX_RECORDED_DEPTH];
     int nrec = 0;
     f3 term_Li = mk3(0.0f);
     int sw_k = -1;                                          // next vertex the sweep consumes
     SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
-    uint32_t it = w.s_begin;
+    uint32_t next_sample = (__ballot(w.valid) != 0ull) ? w.s_begin : w.s_end;
+    PrimaryQueue pq = queue_init(io);
+    f3 unused_sum = mk3(0.0f);
     bool alive = false;
-    PathState ps;
+    PathState ps; Interaction it;
     ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
     ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
+    it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
     for (;;) {
-        if (!alive && w.valid && it < w.s_end) {
-            ps.smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
-            pixel_ray<SK>(R, C, ps.smp, w.x, w.y, ps.o, ps.d);
-            ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
+        if (pq.tail - pq.head < (uint32_t)__popcll(__ballot(!alive)) && next_sample < w.s_end)
+            primary_refill<SK, A, true, false, ENV>(S, R, C, lds, w.x, w.y, w.valid, perm_seed, next_sample, w.s_end, pq, unused_sum, cnt);
+        const int took = primary_pop<SK>(S, C, !alive, lds_perm, w.x - (lane & 7), w.y - (lane >> 3), pq, ps, it);
+        if (took >= 0) {
+            le_grad = mk3(lds_leg[took], lds_leg[took + WAVE], lds_leg[took + 2 * WAVE]);   // cotangent of the path's pixel
             nrec = 0; term_Li = mk3(0.0f);
-            alive = true; it++;
+            alive = true;
         }
-        if (__ballot(alive) == 0ull) break;
+        if (__ballot(alive) == 0ull) {
+            if (next_sample >= w.s_end) break;
+            continue;
+        }
         if (alive) {
-            PathVertex pv; bool has_vertex; float term_plfrac = 0.0f;
-            bool done = path_bounce<SK, A, true, false, ENV>(S, R, C, io, lds, ps, pv, has_vertex, term_Li, cnt, &term_plfrac);
-            if (has_vertex) {
+            PathVertex pv; float term_plfrac = 0.0f;
+            bool done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, cnt);
+            {
                 PackedVertex p = pack_vertex(pv, le_grad);
                 if (nrec < lds_vertices) {
                     float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
@@ -166,6 +201,10 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
                     lds_dlnp[nrec * WAVE + lane] = p.e.w;
                 } else deep[nrec] = p;
                 nrec++;
+            }
+            if (!done) {
+                Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+                done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac);
             }
             if (done) {
                 alive = false;

@@ -6,6 +6,7 @@ import torch
 
 import oracle
 from conftest import CBOX_CAMERA, cbox_material_np, fd_material_np
+from zdr_amd.mathtypes import Camera, float3
 from gpu_util import (TERRAIN_CAMERA, assert_grad_parity, assert_image_parity, make_scene, oracle_params, terrain_arrays)
 
 pytestmark = pytest.mark.gpu
@@ -119,6 +120,34 @@ def test_shard_unions(mat_a):
     for rect in [(0, 0, 64, 32), (0, 32, 64, 64)]:
         scene.render_backward(ones, g_acc, m, (W, W), spp, 4, rect=rect)
     torch.testing.assert_close(g_acc, g_full, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("integrator", ["collocated", "direct", "path"])
+def test_tile_masks_cull_nothing_that_can_be_hit(integrator, mat_a, monkeypatch):
+    """Camera rays of a tile test only the triangle pairs in the tile's mask (k_tile_masks).  The mask may keep
+    too much, never too little: images are bit-identical (gradients up to atomic ordering) with the masks off, for
+    cameras inside the box, tilted, with a wide field of view, and with the tent filter's half-pixel reach."""
+    m = torch.from_numpy(mat_a).cuda()
+    cams = [(CBOX_CAMERA[0], CBOX_CAMERA[1], CBOX_CAMERA[2], CBOX_CAMERA[3]),
+            (1.9, (0.3, 1.2, -1.0), (-0.4, 2.0, -4.0), (0.2, 1.0, 0.1)),          # inside the box, rolled, wide
+            (0.35, (0.0, 2.7, 6.0), (1.5, 0.3, -3.0), (0.0, 1.0, 0.0)),           # narrow, looking at a box corner
+            (1.2, (0.0, 2.7, -3.0), (0.0, 2.7, 5.0), (0.0, 1.0, 0.0))]            # looking out of the open side
+    for k, (fov, o, t, up) in enumerate(cams):
+        for tent in (False, True):
+            scene = make_scene(integrator, accel="brute")
+            scene.camera = Camera(fov=fov, origin=float3(*o), target=float3(*t), up=float3(*up))
+            scene.use_tent_filter = tent
+            W, H, spp = 72, 56, 4
+            ones = torch.ones((H, W, 4), device="cuda")
+            monkeypatch.delenv("ZDR_NO_TILE_MASKS", raising=False)
+            img = scene.render_forward(m, (W, H), spp, 10 + k)
+            g = torch.zeros_like(m); scene.render_backward(ones, g, m, (W, H), spp, 10 + k)
+            monkeypatch.setenv("ZDR_NO_TILE_MASKS", "1")
+            img0 = scene.render_forward(m, (W, H), spp, 10 + k)
+            g0 = torch.zeros_like(m); scene.render_backward(ones, g0, m, (W, H), spp, 10 + k)
+            assert torch.equal(img, img0), (integrator, k, tent)
+            torch.testing.assert_close(g, g0, rtol=1e-4, atol=1e-6)   # float atomics: same terms, free order
+            if k == 0: assert float(img[..., :3].sum()) > 0.0
 
 
 def test_stats_match_oracle_counters(cbox_oracle, mat_a):

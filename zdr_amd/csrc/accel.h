@@ -97,6 +97,28 @@ struct BruteAccel {
         hit_barycentrics(S, h, o, d);
         return h;
     }
+    // Camera rays of one 8x8 tile: only the pairs whose bit is set in the tile's mask can be hit
+    // (k_tile_masks); the mask is wave-uniform, so the walk over its set bits is scalar code.
+    ZD static Hit closest_camera(const DScene &S, int *, f3 o, f3 d, unsigned long long mask) {
+        if (S.ntris > 128) return closest(S, nullptr, o, d, 0.0f, 1e30f);   // more pairs than mask bits
+        Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = 1e30f;
+        const_v4f_ptr base = as_constant(S.pairs);
+        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mask), hi = __builtin_amdgcn_readfirstlane((unsigned)(mask >> 32));
+        unsigned long long m = ((unsigned long long)hi << 32) | lo;
+#pragma unroll 1
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1ull;
+            PairHit ph = pair_test(base + 6 * k, o, d);
+            const int s = 2 * k;
+            bool ok = (ph.t.x > 0.0f) & (ph.t.x < h.t) & (ph.c.x >= 0.0f);
+            h.t = ok ? ph.t.x : h.t; h.slot = ok ? s : h.slot;
+            ok = (ph.t.y > 0.0f) & (ph.t.y < h.t) & (ph.c.y >= 0.0f);
+            h.t = ok ? ph.t.y : h.t; h.slot = ok ? s + 1 : h.slot;
+        }
+        hit_barycentrics(S, h, o, d);
+        return h;
+    }
     ZD static bool any(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         bool occ = false;
         const_v4f_ptr q = as_constant(S.pairs);
@@ -122,6 +144,7 @@ ZD float box_entry(float lox, float loy, float loz, float hix, float hiy, float 
 
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
+    ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
     // 4-wide BVH, one 128-byte node per visit (8 dwordx4 loads of one line), nearest hit child first.
     // stack: this wave's LDS region, ZDR_BVH_STACK x 64 ints; entry e of lane l at stack[e * 64 + l].
     // A work item is (id, cnt): cnt == 0 -> node id, cnt > 0 -> leaf slots [id, id + cnt); cnt < 0 -> unused child.

@@ -41,9 +41,9 @@ ZD float4 brdf_grad(float cz_over_pi, float dfdr, f3 ct) {     // d(f cos)[ct] w
 // BWD: the vertex gradient is returned through (guv, grad) — grad stays 0 when there is nothing to add —
 // and the caller queues it at a reconverged point (scene.h, ScatterQueue).
 template <class A, bool BWD, bool STATS>
-ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io, int *lds, f3 o, f3 d, f3 le_grad, Counters &cnt, f2 &guv, float4 &grad) {
+ZD f3 collocated_sample(const DScene &S, const RenderCfg &R, const KernelIO &io, int *lds, f3 o, f3 d, unsigned long long cam_mask, f3 le_grad, Counters &cnt, f2 &guv, float4 &grad) {
     COUNT(C_CLOSEST);
-    Hit h = A::closest(S, lds, o, d, 0.0f, 1e30f);
+    Hit h = A::closest_camera(S, lds, o, d, cam_mask);
     if (h.slot < 0) return mk3(0.0f);
     COUNT(C_HITS);
     Interaction it = surface_interact(S, h);
@@ -95,9 +95,9 @@ ZD float4 uvgrad_sample(const DScene &S, int *lds, f3 o, f3 d, f3 odx, f3 ddx, f
 // direct.py:21-85 (forward) / 89-167 (adjoint; gradient written once at the primary uv, App. B-11)
 template <int SK, class A, bool BWD, bool STATS, bool ENV>
 ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                    Sampler &smp, f3 o, f3 d, f3 le_grad, Counters &cnt, f2 &guv, float4 &grad) {
+                    Sampler &smp, f3 o, f3 d, unsigned long long cam_mask, f3 le_grad, Counters &cnt, f2 &guv, float4 &grad) {
     COUNT(C_CLOSEST);
-    Hit h = A::closest(S, lds, o, d, 0.0f, 1e30f);
+    Hit h = A::closest_camera(S, lds, o, d, cam_mask);
     if (h.slot < 0) return (ENV && S.env_count > 0) ? env_lookup(S, direction_to_uv(d)) : mk3(0.0f);   // direct.py:23-24
     COUNT(C_HITS);
     Interaction it = surface_interact(S, h);
@@ -334,7 +334,7 @@ ZD uint32_t lane_rank(unsigned long long mask) {               // number of set 
 // at the camera ray (miss, emitter, back face) are finished at once: their radiance goes to `sum`,
 // this lane's own pixel.
 template <int SK, class A, bool BWD, bool STATS, bool ENV>
-ZD void primary_refill(const DScene &S, const RenderCfg &R, const SamplerCfg &C, int *lds, int x, int y, bool valid,
+ZD void primary_refill(const DScene &S, const RenderCfg &R, const SamplerCfg &C, int *lds, int x, int y, bool valid, unsigned long long cam_mask,
                        uint32_t perm_seed, uint32_t &next_sample, uint32_t s_end, PrimaryQueue &q, f3 &sum, Counters &cnt) {
     for (int b = 0; b < ZDR_RING_BATCH && next_sample < s_end; b++, next_sample++) {   // wave-uniform
         bool park = false;
@@ -345,7 +345,7 @@ ZD void primary_refill(const DScene &S, const RenderCfg &R, const SamplerCfg &C,
             pixel_ray<SK>(R, C, ps.smp, x, y, ps.o, ps.d);
             ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;   // prb.py:20-22
             COUNT(C_SAMPLES); COUNT(C_CLOSEST);
-            Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+            Hit h = A::closest_camera(S, lds, ps.o, ps.d, cam_mask);
             Interaction it; f3 tl;
             if (path_arrive<false, STATS, ENV>(S, ps, h, it, tl, cnt)) {
                 if (!BWD) {                                                     // a path without vertices has no gradient

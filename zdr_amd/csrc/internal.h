@@ -9,7 +9,7 @@
 
 // primary ring (integrators.h): parked camera-ray vertices per lane, and camera samples generated per refill
 #ifndef ZDR_RING_CAP
-#define ZDR_RING_CAP 32
+#define ZDR_RING_CAP 16
 #endif
 #ifndef ZDR_RING_BATCH
 #define ZDR_RING_BATCH 8
@@ -39,6 +39,7 @@ struct KernelIO {
     float *d_material;                // backward: += gathered from the staging cells by k_cells_to_grad
     float *cells;                     // backward: (tex_h + 1) x (tex_w + 1) staging cells of 16 floats, zeroed per call
     unsigned long long *counters;     // stats variant: 8 counters
+    const unsigned long long *tile_masks;   // brute-force accel: per 8x8 tile, the triangle pairs its camera rays can hit (k_tile_masks); null = all
     float4 *ring;                     // path integrator: per-block rings of parked camera-ray vertices (integrators.h)
 };
 

@@ -27,6 +27,7 @@ ZD float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 ZD float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 ZD f3 operator/(f3 a, float s) { float r = rcp(s); return mk3(a.x * r, a.y * r, a.z * r); }
 ZD f3 normalize(f3 a) { return a * rsq(dot(a, a)); }
+ZD float length(f3 a) { return fsqrt(dot(a, a)); }
 ZD bool any_nan(f3 a) { return (a.x != a.x) | (a.y != a.y) | (a.z != a.z); }
 ZD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 ZD int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }

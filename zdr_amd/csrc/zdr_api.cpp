@@ -248,6 +248,7 @@ struct zdr_scene {
     uint32_t *d_pmj = nullptr; uint16_t *d_bn = nullptr; SamplerTables tab{};
     float4 *d_env_tex = nullptr; float *d_alias_prob = nullptr, *d_env_pdf = nullptr; int32_t *d_alias_idx = nullptr;
     float4 *d_partial = nullptr; size_t partial_bytes = 0;
+    unsigned long long *d_tile_masks = nullptr; size_t tile_mask_bytes = 0;   // camera-ray candidate pairs per tile (k_tile_masks)
     float4 *d_ring = nullptr; size_t ring_bytes = 0;     // primary rings of the path kernels (integrators.h)
     float *d_cells = nullptr; size_t cells_bytes = 0;       // backward staging cells, (tex_h+1) x (tex_w+1) x 16 floats
     unsigned long long *d_counters = nullptr;
@@ -401,7 +402,7 @@ extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
-    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
+    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
     delete s;
     return ZDR_OK;
 }
@@ -524,7 +525,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     R.tiles_x = (p->x1 - p->x0 + 7) / 8; R.tiles_y = (p->y1 - p->y0 + 7) / 8;
     uint32_t ns = p->sample_end - p->sample_begin;
     long tiles = (long)R.tiles_x * R.tiles_y;
-    long target_waves = 16384;
+    long target_waves = 32768;            // measured on cbox 512^2 spp 256: 8192 14.0/22.1 ms, 16384 12.1/20.3, 32768 11.5/19.1, 65536 11.7/19.3
     if (const char *e = getenv("ZDR_TARGET_WAVES")) target_waves = std::max(1L, atol(e));
     uint32_t min_chunk = 16;
     if (const char *e = getenv("ZDR_MIN_CHUNK")) min_chunk = (uint32_t)std::max(1L, atol(e));
@@ -550,7 +551,7 @@ static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
 }
 
 // One FIFO of ZDR_RING_CAP x 64 parked camera-ray vertices per block of the launch
-// (two float4 each): 64 KiB per block, about 1 GiB at the default 16384 blocks, whatever the spp.
+// (two float4 each): 32 KiB per block, about 1 GiB at the default 32768 blocks, whatever the spp.
 static int ensure_ring(zdr_scene *s, const RenderCfg &R) {
     size_t nblocks = (((size_t)R.tiles_x * R.tiles_y * R.nchunks + 7) >> 3) << 3;
     size_t need = nblocks * ZDR_RING_CAP * 2 * 64 * sizeof(float4);
@@ -588,6 +589,17 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     }
     KernelIO io; memset(&io, 0, sizeof io);
     io.ring = s->d_ring;
+    // brute-force scenes of at most 64 triangle pairs: camera rays test only the pairs their tile can see
+    const bool masks = !s->accel_is_bvh && s->ds.ntris <= 128 && p->integrator != ZDR_UVGRAD && !getenv("ZDR_NO_TILE_MASKS");
+    if (masks) {
+        size_t need = (size_t)R.tiles_x * R.tiles_y * sizeof(unsigned long long);
+        if (need > s->tile_mask_bytes) {
+            (void)hipFree(s->d_tile_masks); s->d_tile_masks = nullptr; s->tile_mask_bytes = 0;
+            HIPCHK(hipMalloc((void **)&s->d_tile_masks, need));
+            s->tile_mask_bytes = need;
+        }
+        io.tile_masks = s->d_tile_masks;
+    }
     io.material = (const float4 *)material; io.image = (float4 *)image; io.partial = s->d_partial;
     io.d_image = (const float4 *)d_image; io.d_material = d_material; io.cells = s->d_cells; io.counters = s->d_counters;
     // every pointer a kernel variant dereferences must be live before anything is launched

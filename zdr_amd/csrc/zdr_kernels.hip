@@ -18,7 +18,7 @@
 #define ZDR_MIN_WAVES_BWD ZDR_MIN_WAVES
 #endif
 
-struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk; };
+struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk, tile; };
 
 ZD WorkItem decode_block(const RenderCfg &R) {
     const int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
@@ -29,6 +29,7 @@ ZD WorkItem decode_block(const RenderCfg &R) {
     w.valid = logical < nblocks;
     const int tile = logical / R.nchunks;
     w.chunk = logical - tile * R.nchunks;
+    w.tile = w.valid ? tile : 0;
     const int ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
     const int lane = threadIdx.x;
     w.x = R.x0 + tx * 8 + (lane & 7);
@@ -39,6 +40,13 @@ ZD WorkItem decode_block(const RenderCfg &R) {
     uint32_t e = w.s_begin + R.chunk;
     w.s_end = (e < R.sample_end) ? e : R.sample_end;
     return w;   // the sample range is wave-uniform; lanes outside the shard are masked with w.valid
+}
+
+// candidate triangle pairs of this wave's camera rays (BruteAccel::closest_camera): the tile's mask, or every pair
+ZD unsigned long long camera_mask(const DScene &S, const KernelIO &io, const WorkItem &w) {
+    const int npairs = (S.ntris + 1) >> 1;
+    const unsigned long long all = (npairs >= 64) ? ~0ull : ((1ull << npairs) - 1ull);
+    return io.tile_masks ? io.tile_masks[w.tile] : all;
 }
 
 ZD void store_pixel(const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, const WorkItem &w, f3 sum) {
@@ -73,6 +81,45 @@ ZD void flush_counters(const KernelIO &io, const Counters &cnt) {
     }
 }
 
+// --------------------------------------------------------------------------- tile masks
+// One wave per 8x8 tile, lane = triangle pair: bit k of the tile's mask is set unless BOTH triangles
+// of pair k lie entirely outside one side plane of the tile's camera frustum (or behind the camera).
+// The frustum is padded by one pixel: the tent filter (camera.py:20-31) moves a sample up to half a
+// pixel outside its pixel.  Conservative by construction — a set bit only costs a test.
+__global__ __launch_bounds__(WAVE) void k_tile_masks(DScene S, RenderCfg R, unsigned long long *masks) {
+    const int tile = blockIdx.x, ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x, lane = threadIdx.x;
+    const float X0 = (float)(R.x0 + tx * 8) - 1.0f, X1 = (float)(R.x0 + tx * 8 + 8) + 1.0f;
+    const float Y0 = (float)(R.y0 + ty * 8) - 1.0f, Y1 = (float)(R.y0 + ty * 8 + 8) + 1.0f;
+    const f3 right = ld3(R.cam_right), upp = ld3(R.cam_upp), fwd = ld3(R.cam_fwd), co = ld3(R.cam_o);
+    auto dir = [&](float X, float Y) {                      // pixel_ray without the normalisation
+        float px = (R.two_over_w * X - 1.0f) * R.cam_tan, py = ((R.two_over_h * Y - 1.0f) * R.aspect) * R.cam_tan;
+        return (right * px - upp * py) + fwd;
+    };
+    const f3 c00 = dir(X0, Y0), c10 = dir(X1, Y0), c01 = dir(X0, Y1), c11 = dir(X1, Y1);
+    f3 n[4] = { cross(c00, c01), cross(c11, c10), cross(c10, c00), cross(c01, c11) };   // left, right, top, bottom
+    const f3 inside = (c00 + c11) + (c10 + c01);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (dot(n[k], inside) < 0.0f) n[k] = n[k] * -1.0f;
+    const int npairs = (S.ntris + 1) >> 1;
+    bool keep = false;
+    if (lane < npairs) {
+        for (int t = 2 * lane; t < 2 * lane + 2 && t < S.ntris; t++) {
+            const float4 *r = S.shade + 8 * (size_t)t;
+            f3 v0 = xyz(r[0]) - co, v1 = xyz(r[1]) - co, v2 = xyz(r[2]) - co;
+            float vm = fmaxf(fmaxf(length(v0), length(v1)), length(v2));
+            bool culled = (dot(v0, fwd) <= 0.0f) && (dot(v1, fwd) <= 0.0f) && (dot(v2, fwd) <= 0.0f);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float e = -1e-4f * length(n[k]) * vm;
+                culled = culled || ((dot(n[k], v0) < e) && (dot(n[k], v1) < e) && (dot(n[k], v2) < e));
+            }
+            keep = keep || !culled;
+        }
+    }
+    unsigned long long m = __ballot(keep);
+    if (lane == 0) masks[tile] = m;
+}
+
 // ------------------------------------------------------------------------------------- path
 // Forward (and the counting variant).  Two alternating phases per wave:
 //   refill  lane = pixel: ZDR_RING_BATCH camera samples per pixel are generated, traced and classified by the
@@ -99,6 +146,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
     f3 sum = mk3(0.0f);                                     // paths of this lane's pixel that ended at the camera ray
     uint32_t next_sample = (__ballot(w.valid) != 0ull) ? w.s_begin : w.s_end;
     PrimaryQueue q = queue_init(io);
+    const unsigned long long cam_mask = camera_mask(S, io, w);
     bool alive = false; int pix = 0;
     PathState ps; Interaction it;
     ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
@@ -106,7 +154,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
     it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
     for (;;) {
         if (q.tail - q.head < (uint32_t)__popcll(__ballot(!alive)) && next_sample < w.s_end)
-            primary_refill<SK, A, false, STATS, ENV>(S, R, C, lds, w.x, w.y, w.valid, perm_seed, next_sample, w.s_end, q, sum, cnt);
+            primary_refill<SK, A, false, STATS, ENV>(S, R, C, lds, w.x, w.y, w.valid, cam_mask, perm_seed, next_sample, w.s_end, q, sum, cnt);
         const int took = primary_pop<SK>(S, C, !alive, lds_perm, w.x - (lane & 7), w.y - (lane >> 3), q, ps, it);
         if (took >= 0) { alive = true; pix = took; }
         if (__ballot(alive) == 0ull) {
@@ -171,6 +219,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
     SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
     uint32_t next_sample = (__ballot(w.valid) != 0ull) ? w.s_begin : w.s_end;
     PrimaryQueue pq = queue_init(io);
+    const unsigned long long cam_mask = camera_mask(S, io, w);
     f3 unused_sum = mk3(0.0f);
     bool alive = false;
     PathState ps; Interaction it;
@@ -179,7 +228,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
     it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
     for (;;) {
         if (pq.tail - pq.head < (uint32_t)__popcll(__ballot(!alive)) && next_sample < w.s_end)
-            primary_refill<SK, A, true, false, ENV>(S, R, C, lds, w.x, w.y, w.valid, perm_seed, next_sample, w.s_end, pq, unused_sum, cnt);
+            primary_refill<SK, A, true, false, ENV>(S, R, C, lds, w.x, w.y, w.valid, cam_mask, perm_seed, next_sample, w.s_end, pq, unused_sum, cnt);
         const int took = primary_pop<SK>(S, C, !alive, lds_perm, w.x - (lane & 7), w.y - (lane >> 3), pq, ps, it);
         if (took >= 0) {
             le_grad = mk3(lds_leg[took], lds_leg[took + WAVE], lds_leg[took + 2 * WAVE]);   // cotangent of the path's pixel
@@ -248,6 +297,7 @@ __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerC
     f3 le_grad = mk3(0.0f);
     if (BWD) le_grad = load_le_grad(C, io, w);
     ScatterQueue q = scatter_queue_init(lds_q);
+    const unsigned long long cam_mask = camera_mask(S, io, w);
     f3 sum = mk3(0.0f);
     for (uint32_t it = w.s_begin; it < w.s_end; it++) {     // integrator.py:15 (wave-uniform trip count)
         float4 grad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -258,8 +308,8 @@ __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerC
             pixel_ray<SK>(R, C, smp, w.x, w.y, o, d);
             COUNT(C_SAMPLES);
             f3 rad;
-            if (INTEG == ZDR_COLLOCATED) rad = collocated_sample<A, BWD, STATS>(S, R, io, lds, o, d, le_grad, cnt, guv, grad);
-            else rad = direct_sample<SK, A, BWD, STATS, ENV>(S, R, C, io, lds, smp, o, d, le_grad, cnt, guv, grad);
+            if (INTEG == ZDR_COLLOCATED) rad = collocated_sample<A, BWD, STATS>(S, R, io, lds, o, d, cam_mask, le_grad, cnt, guv, grad);
+            else rad = direct_sample<SK, A, BWD, STATS, ENV>(S, R, C, io, lds, smp, o, d, cam_mask, le_grad, cnt, guv, grad);
             if (!any_nan(rad)) sum = sum + clamp_radiance(rad); else COUNT(C_NAN);
         }
         if (BWD) scatter_push(q, io.cells, w.valid && any_nonzero4(grad) && !any_nan4(grad), guv, grad, R.tex_h, R.tex_w, R.debug_no_scatter);
@@ -373,6 +423,8 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     if (nblocks <= 0) return 0;
     dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
     const size_t dyn = accel_is_bvh ? (size_t)S.stack_entries * WAVE * sizeof(int) : 0;
+    if (io.tile_masks)
+        hipLaunchKernelGGL(k_tile_masks, dim3(R.tiles_x * R.tiles_y), dim3(WAVE), 0, st, S, R, (unsigned long long *)io.tile_masks);
     if (C.kind == ZDR_SAMPLER_CMJ) {
         if (accel_is_bvh) launch_integ<0, BvhAccel>(integrator, grid, dyn, st, S, R, C, io, backward, stats);
         else launch_integ<0, BruteAccel>(integrator, grid, dyn, st, S, R, C, io, backward, stats);

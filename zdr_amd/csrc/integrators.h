@@ -316,7 +316,7 @@ ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, con
 // "its" pixel happened to have short paths (with one pixel per lane a wave ran until its slowest lane
 // had finished, 25 % of all trips on cbox), and a path of k shaded vertices costs k trips, not k + 1.
 // Entry e of block b: two float4 at queue[(b * CAP * 64 + e % (CAP * 64)) * 2 + {0, 1}]
-//   {d.xyz, u} {v, bits(slot), bits(sampler LCG state), bits(pixel-in-tile << 26 | sample index)}
+//   {d.xyz, u} {v, bits(slot), bits(sampler LCG state), bits(pixel-in-tile << 26 | item bank << 25 | sample index)}
 // Pushes and pops are compacted with ballot/mbcnt, so both sides touch consecutive entries.
 struct PrimaryQueue { float4 *base; uint32_t head, tail; };    // head, tail: wave-uniform entry counters
 #define ZDR_QUEUE_ENTRIES (ZDR_RING_CAP * 64)
@@ -335,7 +335,7 @@ ZD uint32_t lane_rank(unsigned long long mask) {               // number of set 
 // this lane's own pixel.
 template <int SK, class A, bool BWD, bool STATS, bool ENV>
 ZD void primary_refill(const DScene &S, const RenderCfg &R, const SamplerCfg &C, int *lds, int x, int y, bool valid, unsigned long long cam_mask,
-                       uint32_t perm_seed, uint32_t &next_sample, uint32_t s_end, PrimaryQueue &q, f3 &sum, Counters &cnt) {
+                       uint32_t perm_seed, int bank, uint32_t &next_sample, uint32_t s_end, PrimaryQueue &q, f3 &sum, Counters &cnt) {
     for (int b = 0; b < ZDR_RING_BATCH && next_sample < s_end; b++, next_sample++) {   // wave-uniform
         bool park = false;
         float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0;
@@ -355,7 +355,7 @@ ZD void primary_refill(const DScene &S, const RenderCfg &R, const SamplerCfg &C,
             } else {
                 park = true;
                 e0 = make_float4(ps.d.x, ps.d.y, ps.d.z, h.u);
-                e1 = make_float4(h.v, __int_as_float(h.slot), __uint_as_float(ps.smp.state), __uint_as_float(((uint32_t)threadIdx.x << 26) | next_sample));
+                e1 = make_float4(h.v, __int_as_float(h.slot), __uint_as_float(ps.smp.state), __uint_as_float(((uint32_t)threadIdx.x << 26) | ((uint32_t)bank << 25) | next_sample));
             }
         }
         const unsigned long long m = __ballot(park);
@@ -368,9 +368,10 @@ ZD void primary_refill(const DScene &S, const RenderCfg &R, const SamplerCfg &C,
 }
 
 // An idle lane takes the oldest parked vertex that no lower idle lane takes: the path state as it is right
-// after the camera ray.  Returns the pixel (lane index within the tile) the path belongs to, or -1.
+// after the camera ray.  Returns bank * 64 + pixel (lane index within the tile) of the path, or -1.
+// lds_perm[bank * 64 + pixel]: CMJ seed of the pixel; lds_origin[bank * 2 + {0, 1}]: first pixel of the bank's tile.
 template <int SK>
-ZD int primary_pop(const DScene &S, const SamplerCfg &C, bool idle, const uint32_t *lds_perm_seed, int tile_x0, int tile_y0,
+ZD int primary_pop(const DScene &S, const SamplerCfg &C, bool idle, const uint32_t *lds_perm, const int *lds_origin,
                    PrimaryQueue &q, PathState &ps, Interaction &it) {
     const unsigned long long m = __ballot(idle);
     const uint32_t avail = q.tail - q.head, rank = lane_rank(m), want = (uint32_t)__popcll(m);
@@ -384,11 +385,12 @@ ZD int primary_pop(const DScene &S, const SamplerCfg &C, bool idle, const uint32
         ps.d = mk3(a.x, a.y, a.z); ps.o = mk3(0.0f);
         ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
         const uint32_t key = __float_as_uint(b.w);
-        pix = (int)(key >> 26);
-        ps.smp.px = (uint32_t)(tile_x0 + (pix & 7)); ps.smp.py = (uint32_t)(tile_y0 + (pix >> 3));
-        ps.smp.sample_index = key & 0x03ffffffu;
+        const int p = (int)(key >> 26), bank = (int)((key >> 25) & 1u);
+        pix = bank * 64 + p;
+        ps.smp.px = (uint32_t)(lds_origin[bank * 2] + (p & 7)); ps.smp.py = (uint32_t)(lds_origin[bank * 2 + 1] + (p >> 3));
+        ps.smp.sample_index = key & 0x01ffffffu;
         ps.smp.dimension = 2;                                                   // pixel_ray drew one 2-D sample
-        ps.smp.permutation_seed = lds_perm_seed[pix];
+        ps.smp.permutation_seed = lds_perm[pix];
         ps.smp.state = __float_as_uint(b.z);
     }
     q.head += (want < avail) ? want : avail;

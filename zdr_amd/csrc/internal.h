@@ -15,6 +15,8 @@
 #define ZDR_RING_BATCH 8
 #endif
 
+#define ZDR_MAX_PERSISTENT_BLOCKS 8192   // 256 CUs x 4 SIMDs x 8 waves: upper bound of the path kernels' persistent grid
+
 // Wave-uniform launch configuration (kernel argument, lives in SGPRs).
 struct RenderCfg {
     int32_t width, height;
@@ -40,6 +42,7 @@ struct KernelIO {
     float *cells;                     // backward: (tex_h + 1) x (tex_w + 1) staging cells of 16 floats, zeroed per call
     unsigned long long *counters;     // stats variant: 8 counters
     const unsigned long long *tile_masks;   // brute-force accel: per 8x8 tile, the triangle pairs its camera rays can hit (k_tile_masks); null = all
+    unsigned int *work_counters;      // path integrator: 8 item counters, one per XCD, zeroed before the launch (fetch_item)
     float4 *ring;                     // path integrator: per-block rings of parked camera-ray vertices (integrators.h)
 };
 

@@ -249,6 +249,7 @@ struct zdr_scene {
     float4 *d_env_tex = nullptr; float *d_alias_prob = nullptr, *d_env_pdf = nullptr; int32_t *d_alias_idx = nullptr;
     float4 *d_partial = nullptr; size_t partial_bytes = 0;
     unsigned long long *d_tile_masks = nullptr; size_t tile_mask_bytes = 0;   // camera-ray candidate pairs per tile (k_tile_masks)
+    unsigned int *d_work_counters = nullptr;
     float4 *d_ring = nullptr; size_t ring_bytes = 0;     // primary rings of the path kernels (integrators.h)
     float *d_cells = nullptr; size_t cells_bytes = 0;       // backward staging cells, (tex_h+1) x (tex_w+1) x 16 floats
     unsigned long long *d_counters = nullptr;
@@ -402,7 +403,7 @@ extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
-    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
+    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
     delete s;
     return ZDR_OK;
 }
@@ -550,16 +551,17 @@ static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
     return ZDR_OK;
 }
 
-// One FIFO of ZDR_RING_CAP x 64 parked camera-ray vertices per block of the launch
-// (two float4 each): 32 KiB per block, about 1 GiB at the default 32768 blocks, whatever the spp.
-static int ensure_ring(zdr_scene *s, const RenderCfg &R) {
-    size_t nblocks = (((size_t)R.tiles_x * R.tiles_y * R.nchunks + 7) >> 3) << 3;
-    size_t need = nblocks * ZDR_RING_CAP * 2 * 64 * sizeof(float4);
+// Workspace of the path kernels: one FIFO of ZDR_RING_CAP x 64 parked camera-ray vertices (two float4 each,
+// 32 KiB) per persistent workgroup, and the eight item counters the workgroups draw from (zeroed per launch).
+static int ensure_ring(zdr_scene *s, hipStream_t st) {
+    size_t need = (size_t)ZDR_MAX_PERSISTENT_BLOCKS * ZDR_RING_CAP * 2 * 64 * sizeof(float4);
     if (need > s->ring_bytes) {
-        (void)hipFree(s->d_ring); s->d_ring = nullptr; s->ring_bytes = 0;
+        (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); s->d_ring = nullptr; s->ring_bytes = 0;
         HIPCHK(hipMalloc((void **)&s->d_ring, need));
         s->ring_bytes = need;
     }
+    if (!s->d_work_counters) HIPCHK(hipMalloc((void **)&s->d_work_counters, 8 * sizeof(unsigned int)));
+    HIPCHK(hipMemsetAsync(s->d_work_counters, 0, 8 * sizeof(unsigned int), st));
     return ZDR_OK;
 }
 
@@ -584,11 +586,11 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (backward) { rc = ensure_cells(s, R, (hipStream_t)stream); if (rc) return rc; }
     else if (!stats) { rc = ensure_partial(s, R); if (rc) return rc; }
     if (p->integrator == ZDR_PATH) {
-        if (p->spp > (1u << 26)) return fail(ZDR_E_UNSUPPORTED, "path integrator: spp above 2^26");   // queue entries pack pixel << 26 | sample
-        rc = ensure_ring(s, R); if (rc) return rc;
+        if (p->spp > (1u << 25)) return fail(ZDR_E_UNSUPPORTED, "path integrator: spp above 2^25");   // queue entries pack pixel << 26 | bank << 25 | sample
+        rc = ensure_ring(s, (hipStream_t)stream); if (rc) return rc;
     }
     KernelIO io; memset(&io, 0, sizeof io);
-    io.ring = s->d_ring;
+    io.ring = s->d_ring; io.work_counters = s->d_work_counters;
     // brute-force scenes of at most 64 triangle pairs: camera rays test only the pairs their tile can see
     const bool masks = !s->accel_is_bvh && s->ds.ntris <= 128 && p->integrator != ZDR_UVGRAD && !getenv("ZDR_NO_TILE_MASKS");
     if (masks) {
@@ -607,7 +609,7 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (!backward && !stats && !io.image) return fail(ZDR_E_INVALID, "forward needs an image");
     if (!backward && !stats && R.nchunks > 1 && !io.partial) return fail(ZDR_E_NOMEM, "chunk workspace missing");
     if (stats && !io.counters) return fail(ZDR_E_NOMEM, "counter buffer missing");
-    if (p->integrator == ZDR_PATH && !io.ring) return fail(ZDR_E_NOMEM, "primary ring workspace missing");
+    if (p->integrator == ZDR_PATH && (!io.ring || !io.work_counters)) return fail(ZDR_E_NOMEM, "path workspace missing");
     if (stats && p->integrator == ZDR_UVGRAD) return fail(ZDR_E_UNSUPPORTED, "no statistics for render_duvdxy");
     if (zdr_launch_render(s->ds, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
         return fail(ZDR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(hipGetLastError()));

@@ -5,6 +5,8 @@
 // the hardware can retire/dispatch waves individually (paths have very uneven lengths).  The
 // block index is remapped so that each XCD (blocks b, b+8, ... share one) receives a contiguous
 // run of tiles: primary-hit texel footprints of neighbouring tiles then share that XCD's L2.
+#include <algorithm>
+#include <cstdlib>
 #include "integrators.h"
 #include "zdr.h"
 
@@ -20,16 +22,14 @@
 
 struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk, tile; };
 
-ZD WorkItem decode_block(const RenderCfg &R) {
+// Work item `logical` = (tile, sample chunk); consecutive items are the chunks of one tile, then the next tile.
+ZD WorkItem decode_item(const RenderCfg &R, int logical) {
     const int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
-    const int per_xcd = (nblocks + 7) >> 3;
-    const int b = blockIdx.x;
-    const int logical = (b & 7) * per_xcd + (b >> 3);       // XCD-contiguous tile runs
     WorkItem w;
-    w.valid = logical < nblocks;
-    const int tile = logical / R.nchunks;
-    w.chunk = logical - tile * R.nchunks;
-    w.tile = w.valid ? tile : 0;
+    w.valid = logical >= 0 && logical < nblocks;
+    const int tile = w.valid ? logical / R.nchunks : 0;
+    w.chunk = w.valid ? logical - tile * R.nchunks : 0;
+    w.tile = tile;
     const int ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
     const int lane = threadIdx.x;
     w.x = R.x0 + tx * 8 + (lane & 7);
@@ -40,6 +40,35 @@ ZD WorkItem decode_block(const RenderCfg &R) {
     uint32_t e = w.s_begin + R.chunk;
     w.s_end = (e < R.sample_end) ? e : R.sample_end;
     return w;   // the sample range is wave-uniform; lanes outside the shard are masked with w.valid
+}
+
+// one workgroup per item (direct / collocated / uvgrad kernels): XCD-contiguous tile runs
+ZD WorkItem decode_block(const RenderCfg &R) {
+    const int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
+    const int per_xcd = (nblocks + 7) >> 3;
+    const int b = blockIdx.x;
+    const int logical = (b & 7) * per_xcd + (b >> 3);
+    return decode_item(R, logical < nblocks ? logical : -1);
+}
+
+// Persistent waves (path kernels) draw items from eight counters, one per XCD: a wave on XCD x
+// (workgroups are dealt round-robin, x = blockIdx.x & 7) walks x's contiguous run of tiles, so the texel
+// footprints of neighbouring tiles share that XCD's L2; when its own run is used up it takes from the others.
+// Wave-uniform; returns -1 when no item is left.  Counters only grow, by at most 8 per call.
+ZD int fetch_item(const RenderCfg &R, unsigned int *counters) {
+    const int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
+    const int per_xcd = (nblocks + 7) >> 3;
+    int got = -1;
+    if (threadIdx.x == 0) {
+        const int x = blockIdx.x & 7;
+        for (int j = 0; j < 8 && got < 0; j++) {
+            const int y = (x + j) & 7;
+            const unsigned int local = atomicAdd(&counters[y], 1u);
+            const long long logical = (long long)y * per_xcd + local;
+            if (local < (unsigned int)per_xcd && logical < nblocks) got = (int)logical;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(got);
 }
 
 // candidate triangle pairs of this wave's camera rays (BruteAccel::closest_camera): the tile's mask, or every pair
@@ -121,70 +150,124 @@ __global__ __launch_bounds__(WAVE) void k_tile_masks(DScene S, RenderCfg R, unsi
 }
 
 // ------------------------------------------------------------------------------------- path
-// Forward (and the counting variant).  Two alternating phases per wave:
-//   refill  lane = pixel: ZDR_RING_BATCH camera samples per pixel are generated, traced and classified by the
-//           whole wave and the vertices to shade are parked in the wave's FIFO (integrators.h);
-//   flat loop  a lane is just a worker: it takes the next parked vertex (of ANY pixel of the tile) and
-//           each trip shades one vertex:  shade -> shadow ray -> BSDF sample -> trace -> classify.
-// Radiance of a finished path goes to its pixel's accumulator in LDS (ds_add_f32; one wave, program
-// order, so the sum is reproducible).
+// Forward (and the counting variant).  PERSISTENT waves: the grid is what the chip holds at once, and each
+// wave draws work items (tile x sample chunk) until none is left.  Two alternating phases:
+//   refill  lane = pixel: ZDR_RING_BATCH camera samples per pixel of the current item are generated, traced
+//           and classified by the whole wave and the vertices to shade are parked in the wave's FIFO;
+//   flat loop  a lane is just a worker: it takes the next parked vertex (of ANY pixel) and each trip
+//           shades one vertex:  shade -> shadow ray -> BSDF sample -> trace -> classify.
+// Items overlap: when the current item has no camera sample left the wave starts the next one while the last
+// paths of the old one are still running, so lanes never wait for a tile's longest path.  Per-pixel state
+// (radiance sums, CMJ seeds) therefore lives in LDS in two banks, item n in bank n & 1; a path carries its
+// bank and pixel.  Radiance is added with ds_add_f32 — one wave, program order, so sums are reproducible.
+struct ItemBanks {
+    int logical[2];          // item held by each bank, -1 = free (wave-uniform)
+    uint32_t inflight[2];    // parked + running paths of each bank (wave-uniform)
+};
+
 template <int SK, class A, bool STATS, bool ENV>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
-    __shared__ uint32_t lds_perm[WAVE];
-    __shared__ float lds_sum[3 * WAVE];
+    __shared__ uint32_t lds_perm[2 * WAVE];
+    __shared__ int lds_origin[4];
+    __shared__ float lds_sum[2 * 3 * WAVE];
     const int lane = threadIdx.x;
-    const WorkItem w = decode_block(R);
-    const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
-    lds_perm[lane] = perm_seed;
-    lds_sum[lane] = 0.0f; lds_sum[lane + WAVE] = 0.0f; lds_sum[lane + 2 * WAVE] = 0.0f;
-    __syncthreads();
     Counters cnt;
 #pragma unroll
     for (int i = 0; i < 8; i++) cnt.c[i] = 0;
     PathVertex pv; f3 term_Li = mk3(0.0f);
-    f3 sum = mk3(0.0f);                                     // paths of this lane's pixel that ended at the camera ray
-    uint32_t next_sample = (__ballot(w.valid) != 0ull) ? w.s_begin : w.s_end;
+    ItemBanks ib; ib.logical[0] = ib.logical[1] = -1; ib.inflight[0] = ib.inflight[1] = 0;
+    int bank = 1;                                           // bank of the current item (the first fetch flips it to 0)
+    bool more_items = true;
+    WorkItem w = decode_item(R, -1);
+    uint32_t next_sample = 0, s_end = 0, perm_seed = 0;
+    unsigned long long cam_mask = 0ull;
+    f3 sum = mk3(0.0f);                                     // current item, this lane's pixel: paths that ended at the camera ray
     PrimaryQueue q = queue_init(io);
-    const unsigned long long cam_mask = camera_mask(S, io, w);
-    bool alive = false; int pix = 0;
+    bool alive = false; int pix = 0;                        // pix: bank * 64 + pixel of the running path
     PathState ps; Interaction it;
     ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
     ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
     it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
+    int stall = 0;
     for (;;) {
-        if (q.tail - q.head < (uint32_t)__popcll(__ballot(!alive)) && next_sample < w.s_end)
-            primary_refill<SK, A, false, STATS, ENV>(S, R, C, lds, w.x, w.y, w.valid, cam_mask, perm_seed, next_sample, w.s_end, q, sum, cnt);
-        const int took = primary_pop<SK>(S, C, !alive, lds_perm, w.x - (lane & 7), w.y - (lane >> 3), q, ps, it);
+        bool progress = false;
+        if (q.tail - q.head < (uint32_t)__popcll(__ballot(!alive))) {          // the FIFO cannot serve every idle lane
+            if (next_sample < s_end) {
+                progress = true;
+                const uint32_t t0 = q.tail;
+                primary_refill<SK, A, false, STATS, ENV>(S, R, C, lds, w.x, w.y, w.valid, cam_mask, perm_seed, bank, next_sample, s_end, q, sum, cnt);
+                ib.inflight[bank] += q.tail - t0;
+            } else if (more_items && ib.logical[bank ^ 1] < 0) {                // next item, into the free bank
+                if (ib.logical[bank] >= 0) {                                    // park the register part of the old item's sums
+                    atomicAdd(&lds_sum[(bank * 3 + 0) * WAVE + lane], sum.x); atomicAdd(&lds_sum[(bank * 3 + 1) * WAVE + lane], sum.y);
+                    atomicAdd(&lds_sum[(bank * 3 + 2) * WAVE + lane], sum.z);
+                    sum = mk3(0.0f);
+                }
+                const int nxt = fetch_item(R, io.work_counters);
+                if (nxt < 0) more_items = false;
+                else {
+                    bank ^= 1;
+                    ib.logical[bank] = nxt;
+                    w = decode_item(R, nxt);
+                    perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
+                    cam_mask = camera_mask(S, io, w);
+                    lds_perm[bank * WAVE + lane] = perm_seed;
+                    if (lane == 0) { lds_origin[bank * 2] = w.x; lds_origin[bank * 2 + 1] = w.y; }
+                    lds_sum[(bank * 3 + 0) * WAVE + lane] = 0.0f; lds_sum[(bank * 3 + 1) * WAVE + lane] = 0.0f; lds_sum[(bank * 3 + 2) * WAVE + lane] = 0.0f;
+                    __syncthreads();
+                    next_sample = w.s_begin; s_end = w.s_end;
+                }
+                stall = 0;
+                continue;
+            }
+        }
+        const int took = primary_pop<SK>(S, C, !alive, lds_perm, lds_origin, q, ps, it);
         if (took >= 0) { alive = true; pix = took; }
-        if (__ballot(alive) == 0ull) {
-            if (next_sample >= w.s_end) break;              // queue empty (idle lanes would have popped), nothing left to generate
-            continue;                                       // every sample of the batch ended at the camera ray
-        }
-        if (alive) {
-            bool done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, cnt);
-            if (!done) {
-                COUNT(C_CLOSEST);
-                Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
-                done = path_arrive<false, STATS, ENV>(S, ps, h, it, term_Li, cnt);
+        if (__ballot(alive) != 0ull) {
+            progress = true;
+            bool done = false;
+            if (alive) {
+                done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, cnt);
+                if (!done) {
+                    COUNT(C_CLOSEST);
+                    Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+                    done = path_arrive<false, STATS, ENV>(S, ps, h, it, term_Li, cnt);
+                }
+                if (done) {
+                    alive = false;
+                    if (!any_nan(ps.L)) {                   // integrator.py:27-28
+                        f3 c = clamp_radiance(ps.L);
+                        const int bk = pix >> 6, px = pix & 63;
+                        atomicAdd(&lds_sum[(bk * 3 + 0) * WAVE + px], c.x); atomicAdd(&lds_sum[(bk * 3 + 1) * WAVE + px], c.y);
+                        atomicAdd(&lds_sum[(bk * 3 + 2) * WAVE + px], c.z);
+                    } else COUNT(C_NAN);
+                }
             }
-            if (done) {
-                alive = false;
-                if (!any_nan(ps.L)) {                       // integrator.py:27-28
-                    f3 c = clamp_radiance(ps.L);
-                    atomicAdd(&lds_sum[pix], c.x); atomicAdd(&lds_sum[pix + WAVE], c.y); atomicAdd(&lds_sum[pix + 2 * WAVE], c.z);
-                } else COUNT(C_NAN);
+            ib.inflight[0] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 0));
+            ib.inflight[1] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 1));
+        }
+        // retire finished items: every camera sample generated and no path left
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            if (ib.logical[b] >= 0 && ib.inflight[b] == 0 && (b != bank || next_sample >= s_end)) {
+                __syncthreads();
+                const WorkItem wb = decode_item(R, ib.logical[b]);
+                f3 tot = mk3(lds_sum[(b * 3 + 0) * WAVE + lane], lds_sum[(b * 3 + 1) * WAVE + lane], lds_sum[(b * 3 + 2) * WAVE + lane]);
+                if (b == bank) { tot = tot + sum; sum = mk3(0.0f); }
+                if (!STATS) store_pixel(R, C, io, wb, tot);         // the stats variant owns no image
+                ib.logical[b] = -1;
             }
         }
+        if (__ballot(alive) == 0ull && q.tail == q.head && next_sample >= s_end && !more_items) break;   // both banks are retired by now
+        stall = progress ? 0 : stall + 1;
+        if (stall > 4) break;                               // cannot happen (every branch above makes progress); never spin on the GPU
     }
-    __syncthreads();
-    sum = sum + mk3(lds_sum[lane], lds_sum[lane + WAVE], lds_sum[lane + 2 * WAVE]);
-    if (!STATS) store_pixel(R, C, io, w, sum);              // the stats variant owns no image
     flush_counters<STATS>(io, cnt);
 }
 
 // PRB backward with ONE traversal.  Each trip a live lane shades one vertex of its path (same trip
-// order, primary queue and pixel-free lanes as k_path) and appends it to its record list: vertices before the first Russian-roulette depth (at
+// order, primary queue, pixel-free lanes, persistent waves and item banks as k_path) and appends it to its record list: vertices before the first Russian-roulette depth (at
 // most ZDR_LDS_VERTICES of them) live in LDS laid out [slot][float4][lane] (conflict-free ds_*_b128,
 // 4 float4 + one float), deeper ones (25 % of all vertices on cbox) in per-lane scratch (5 float4).
 // When a path ends, a short wave-uniform loop sweeps its records last to first and queues the
@@ -200,86 +283,121 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
     __shared__ float4 lds_rec[ZDR_LDS_VERTICES * 4 * WAVE];
     __shared__ float lds_dlnp[ZDR_LDS_VERTICES * WAVE];
+    __shared__ uint32_t lds_perm[2 * WAVE];                 // per item bank (see k_path): CMJ seeds, tile origin,
+    __shared__ int lds_origin[4];
+    __shared__ float lds_leg[2 * 3 * WAVE];                 // and the pixel cotangents / spp
     const int lane = threadIdx.x;
     const int lds_vertices = (R.rr_depth < ZDR_LDS_VERTICES) ? max(R.rr_depth, 0) : ZDR_LDS_VERTICES;   // LDS records carry no RR fields
-    const WorkItem w = decode_block(R);
-    const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     Counters cnt;
-    __shared__ uint32_t lds_perm[WAVE];
-    __shared__ float lds_leg[3 * WAVE];
-    f3 le_grad = load_le_grad(C, io, w);                    // of this lane's pixel; a popped path brings its own pixel's
-    lds_perm[lane] = perm_seed;
-    lds_leg[lane] = le_grad.x; lds_leg[lane + WAVE] = le_grad.y; lds_leg[lane + 2 * WAVE] = le_grad.z;
-    __syncthreads();
+    ItemBanks ib; ib.logical[0] = ib.logical[1] = -1; ib.inflight[0] = ib.inflight[1] = 0;
+    int bank = 1;
+    bool more_items = true;
+    WorkItem w = decode_item(R, -1);
+    uint32_t next_sample = 0, s_end = 0, perm_seed = 0;
+    unsigned long long cam_mask = 0ull;
+    f3 le_grad = mk3(0.0f);                                 // cotangent of the running path's pixel
     ScatterQueue q = scatter_queue_init(lds_q);
     PackedVertex deep[ZDR_MAX_RECORDED_DEPTH];
     int nrec = 0;
     f3 term_Li = mk3(0.0f);
     int sw_k = -1;                                          // next vertex the sweep consumes
     SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
-    uint32_t next_sample = (__ballot(w.valid) != 0ull) ? w.s_begin : w.s_end;
     PrimaryQueue pq = queue_init(io);
-    const unsigned long long cam_mask = camera_mask(S, io, w);
     f3 unused_sum = mk3(0.0f);
-    bool alive = false;
+    bool alive = false; int pix = 0;
     PathState ps; Interaction it;
     ps.o = mk3(0.0f); ps.d = mk3(0.0f, 0.0f, 1.0f); ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
     ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
     it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
+    int stall = 0;
     for (;;) {
-        if (pq.tail - pq.head < (uint32_t)__popcll(__ballot(!alive)) && next_sample < w.s_end)
-            primary_refill<SK, A, true, false, ENV>(S, R, C, lds, w.x, w.y, w.valid, cam_mask, perm_seed, next_sample, w.s_end, pq, unused_sum, cnt);
-        const int took = primary_pop<SK>(S, C, !alive, lds_perm, w.x - (lane & 7), w.y - (lane >> 3), pq, ps, it);
+        bool progress = false;
+        if (pq.tail - pq.head < (uint32_t)__popcll(__ballot(!alive))) {
+            if (next_sample < s_end) {
+                const uint32_t t0 = pq.tail;
+                primary_refill<SK, A, true, false, ENV>(S, R, C, lds, w.x, w.y, w.valid, cam_mask, perm_seed, bank, next_sample, s_end, pq, unused_sum, cnt);
+                ib.inflight[bank] += pq.tail - t0;
+                progress = true;
+            } else if (more_items && ib.logical[bank ^ 1] < 0) {
+                const int nxt = fetch_item(R, io.work_counters);
+                if (nxt < 0) more_items = false;
+                else {
+                    bank ^= 1;
+                    ib.logical[bank] = nxt;
+                    w = decode_item(R, nxt);
+                    perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
+                    cam_mask = camera_mask(S, io, w);
+                    const f3 lg = load_le_grad(C, io, w);
+                    lds_perm[bank * WAVE + lane] = perm_seed;
+                    if (lane == 0) { lds_origin[bank * 2] = w.x; lds_origin[bank * 2 + 1] = w.y; }
+                    lds_leg[(bank * 3 + 0) * WAVE + lane] = lg.x; lds_leg[(bank * 3 + 1) * WAVE + lane] = lg.y; lds_leg[(bank * 3 + 2) * WAVE + lane] = lg.z;
+                    __syncthreads();
+                    next_sample = w.s_begin; s_end = w.s_end;
+                }
+                stall = 0;
+                continue;
+            }
+        }
+        const int took = primary_pop<SK>(S, C, !alive, lds_perm, lds_origin, pq, ps, it);
         if (took >= 0) {
-            le_grad = mk3(lds_leg[took], lds_leg[took + WAVE], lds_leg[took + 2 * WAVE]);   // cotangent of the path's pixel
+            const int bk = took >> 6, px = took & 63;
+            le_grad = mk3(lds_leg[(bk * 3 + 0) * WAVE + px], lds_leg[(bk * 3 + 1) * WAVE + px], lds_leg[(bk * 3 + 2) * WAVE + px]);
             nrec = 0; term_Li = mk3(0.0f);
-            alive = true;
+            alive = true; pix = took;
         }
-        if (__ballot(alive) == 0ull) {
-            if (next_sample >= w.s_end) break;
-            continue;
-        }
-        if (alive) {
-            PathVertex pv; float term_plfrac = 0.0f;
-            bool done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, cnt);
-            {
-                PackedVertex p = pack_vertex(pv, le_grad);
-                if (nrec < lds_vertices) {
-                    float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
-                    r[0] = p.a; r[WAVE] = p.b; r[2 * WAVE] = p.c; r[3 * WAVE] = p.d;
-                    lds_dlnp[nrec * WAVE + lane] = p.e.w;
-                } else deep[nrec] = p;
-                nrec++;
-            }
-            if (!done) {
-                Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
-                done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac);
-            }
-            if (done) {
-                alive = false;
-                if (!any_nan(ps.L) && nrec > 0) {           // prb.py:100: NaN paths contribute nothing
-                    sw_k = nrec - 1;
-                    sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f;
-                    sw.tw = term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
+        if (__ballot(alive) != 0ull) {
+            progress = true;
+            bool done = false;
+            if (alive) {
+                PathVertex pv; float term_plfrac = 0.0f;
+                done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, cnt);
+                {
+                    PackedVertex p = pack_vertex(pv, le_grad);
+                    if (nrec < lds_vertices) {
+                        float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
+                        r[0] = p.a; r[WAVE] = p.b; r[2 * WAVE] = p.c; r[3 * WAVE] = p.d;
+                        lds_dlnp[nrec * WAVE + lane] = p.e.w;
+                    } else deep[nrec] = p;
+                    nrec++;
+                }
+                if (!done) {
+                    Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+                    done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac);
+                }
+                if (done) {
+                    alive = false;
+                    if (!any_nan(ps.L) && nrec > 0) {       // prb.py:100: NaN paths contribute nothing
+                        sw_k = nrec - 1;
+                        sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f;
+                        sw.tw = term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
+                    }
                 }
             }
-        }
-        while (__ballot(sw_k >= 0) != 0ull) {               // wave-uniform: sweep every finished path to its first vertex
-            const bool swp = sw_k >= 0;
-            float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            f2 guv; guv.x = 0.0f; guv.y = 0.0f;
-            if (swp) {
-                PackedVertex p;
-                if (sw_k < lds_vertices) {
-                    const float4 *r = lds_rec + (sw_k * 4) * WAVE + lane;
-                    p.a = r[0]; p.b = r[WAVE]; p.c = r[2 * WAVE]; p.d = r[3 * WAVE];
-                    p.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[sw_k * WAVE + lane]);
-                } else p = deep[sw_k];
-                g = sweep_vertex(p, sw, guv);
-                sw_k--;
+            ib.inflight[0] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 0));
+            ib.inflight[1] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 1));
+            while (__ballot(sw_k >= 0) != 0ull) {           // wave-uniform: sweep every finished path to its first vertex
+                const bool swp = sw_k >= 0;
+                float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                f2 guv; guv.x = 0.0f; guv.y = 0.0f;
+                if (swp) {
+                    PackedVertex p;
+                    if (sw_k < lds_vertices) {
+                        const float4 *r = lds_rec + (sw_k * 4) * WAVE + lane;
+                        p.a = r[0]; p.b = r[WAVE]; p.c = r[2 * WAVE]; p.d = r[3 * WAVE];
+                        p.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[sw_k * WAVE + lane]);
+                    } else p = deep[sw_k];
+                    g = sweep_vertex(p, sw, guv);
+                    sw_k--;
+                }
+                scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
             }
-            scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
         }
+#pragma unroll
+        for (int b = 0; b < 2; b++)                         // an item whose samples are all generated and whose paths have ended frees its bank
+            if (ib.logical[b] >= 0 && ib.inflight[b] == 0 && (b != bank || next_sample >= s_end)) ib.logical[b] = -1;
+        if (__ballot(alive) == 0ull && pq.tail == pq.head && next_sample >= s_end && !more_items) break;
+        stall = progress ? 0 : stall + 1;
+        if (stall > 4) break;                               // cannot happen (every branch above makes progress); never spin on the GPU
     }
     scatter_flush(q, io.cells);
 }
@@ -384,19 +502,35 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 }
 
 // ----------------------------------------------------------------------------------- launch
-template <int SK, class A>
-static void launch_path(dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
-    // the environment-light code is a separate instantiation: inside the default kernels it cost 16 % (cbox forward)
-    if (S.env_count > 0) {
-        if (backward) hipLaunchKernelGGL((k_path_bwd<SK, A, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-        else if (stats) hipLaunchKernelGGL((k_path<SK, A, true, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-        else hipLaunchKernelGGL((k_path<SK, A, false, true>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-    } else {
-        if (backward) hipLaunchKernelGGL((k_path_bwd<SK, A, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-        else if (stats) hipLaunchKernelGGL((k_path<SK, A, true, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-        else hipLaunchKernelGGL((k_path<SK, A, false, false>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-    }
+// Persistent grid of the path kernels: as many single-wave workgroups as the chip holds at once (never more
+// than there are items).  A workgroup that is not resident at first simply starts later and draws what is left.
+template <class K>
+static dim3 persistent_grid(K kernel, size_t dyn, int nitems) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, dyn) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (const char *e = getenv("ZDR_PERSISTENT_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    long g = std::min<long>((long)per_cu * cus, (long)ZDR_MAX_PERSISTENT_BLOCKS);
+    return dim3((unsigned)std::max<long>(1, std::min<long>(g, nitems)));
 }
+
+template <int SK, class A>
+static void launch_path(int nitems, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
+    // the environment-light code is a separate instantiation: inside the default kernels it cost 16 % (cbox forward)
+#define ZDR_LAUNCH_PERSISTENT(K) hipLaunchKernelGGL((K), persistent_grid((K), dyn, nitems), dim3(WAVE), dyn, st, S, R, C, io)
+    if (S.env_count > 0) {
+        if (backward) ZDR_LAUNCH_PERSISTENT((k_path_bwd<SK, A, true>));
+        else if (stats) ZDR_LAUNCH_PERSISTENT((k_path<SK, A, true, true>));
+        else ZDR_LAUNCH_PERSISTENT((k_path<SK, A, false, true>));
+    } else {
+        if (backward) ZDR_LAUNCH_PERSISTENT((k_path_bwd<SK, A, false>));
+        else if (stats) ZDR_LAUNCH_PERSISTENT((k_path<SK, A, true, false>));
+        else ZDR_LAUNCH_PERSISTENT((k_path<SK, A, false, false>));
+    }
+#undef ZDR_LAUNCH_PERSISTENT
+}
+
 template <int INTEG, int SK, class A>
 static void launch_simple(dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
     if (INTEG == ZDR_DIRECT && S.env_count > 0) {
@@ -412,7 +546,7 @@ static void launch_simple(dim3 grid, size_t dyn, hipStream_t st, const DScene &S
 template <int SK, class A>
 static void launch_integ(int integrator, dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
     if (integrator == ZDR_UVGRAD) hipLaunchKernelGGL((k_uvgrad<SK, A>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-    else if (integrator == ZDR_PATH) launch_path<SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
+    else if (integrator == ZDR_PATH) launch_path<SK, A>(R.tiles_x * R.tiles_y * R.nchunks, dyn, st, S, R, C, io, backward, stats);
     else if (integrator == ZDR_DIRECT) launch_simple<ZDR_DIRECT, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
     else launch_simple<ZDR_COLLOCATED, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
 }

@@ -131,7 +131,7 @@ ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells) {
 
 // must be called by the whole wave; lanes with active == false push nothing
 ZD void scatter_push(ScatterQueue &q, float *__restrict__ cells, bool active, f2 uv, float4 g, int tex_h, int tex_w, int ablate) {
-    if (ablate) { asm volatile("" ::"v"(g.x), "v"(g.y), "v"(g.z), "v"(g.w), "v"(uv.x), "v"(uv.y)); return; }
+    if (ablate == 1) { asm volatile("" ::"v"(g.x), "v"(g.y), "v"(g.z), "v"(g.w), "v"(uv.x), "v"(uv.y)); return; }
     unsigned long long mask = __ballot(active);
     int n = __popcll(mask);
     if (n == 0) return;
@@ -142,7 +142,7 @@ ZD void scatter_push(ScatterQueue &q, float *__restrict__ cells, bool active, f2
         float ox = px - (float)ix, oy = py - (float)iy;
         int cx = clampi(ix, -1, tex_w - 1) + 1, cy = clampi(iy, -1, tex_h - 1) + 1;
         int slot = q.count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        q.cell[slot] = cx + (tex_w + 1) * cy;
+        q.cell[slot] = (ablate == 2) ? ((cx + (tex_w + 1) * cy) & 1023) : (cx + (tex_w + 1) * cy);   // ablation 2: all atomics hit 64 KiB of L2
         q.g[4 * slot] = g.x; q.g[4 * slot + 1] = g.y; q.g[4 * slot + 2] = g.z; q.g[4 * slot + 3] = g.w;
         q.ox[slot] = ox; q.oy[slot] = oy;
     }

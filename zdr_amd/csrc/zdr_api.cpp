@@ -526,7 +526,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     R.tiles_x = (p->x1 - p->x0 + 7) / 8; R.tiles_y = (p->y1 - p->y0 + 7) / 8;
     uint32_t ns = p->sample_end - p->sample_begin;
     long tiles = (long)R.tiles_x * R.tiles_y;
-    long target_waves = 32768;            // measured on cbox 512^2 spp 256: 8192 14.0/22.1 ms, 16384 12.1/20.3, 32768 11.5/19.1, 65536 11.7/19.3
+    long target_waves = 65536;            // work items (tile x sample chunk) the persistent waves draw; cbox 512^2 spp 256: 16384 11.3/18.5 ms, 32768 10.7/17.7, 65536 10.25/17.2, 131072 10.2/17.1
     if (const char *e = getenv("ZDR_TARGET_WAVES")) target_waves = std::max(1L, atol(e));
     uint32_t min_chunk = 16;
     if (const char *e = getenv("ZDR_MIN_CHUNK")) min_chunk = (uint32_t)std::max(1L, atol(e));

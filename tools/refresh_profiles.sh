@@ -1,0 +1,31 @@
+# Regenerates everything under profiles/ that bench.py and DESIGN.md quote, on the GPU box:
+#   bash tools/refresh_profiles.sh <tag>    -> gpurun_out/<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc.txt, <tag>_pmc_traffic.json
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+tag=${1:-rX}
+bash tools/pmc_passes.sh $tag --which both --iters 2 > gpurun_out/${tag}_pmc.txt 2>&1 || true
+python - <<PY
+import re, json, ast
+rows = {}
+for line in open("gpurun_out/${tag}_pmc.txt"):
+    m = re.match(r"void (k_path(?:_bwd)?)<.*?(\{.*\})\s*$", line)
+    if not m: continue
+    rows.setdefault("k_path_bwd" if m.group(1) == "k_path_bwd" else "k_path_fwd", {}).update({k: float(v) for k, v in ast.literal_eval(m.group(2)).items()})
+out = {"note": "rocprofv3 --pmc passes (tools/pmc_passes.sh), cbox path 512x512 spp256, per launch. FETCH_SIZE/WRITE_SIZE are KiB; traffic = (FETCH_SIZE + WRITE_SIZE) * 1024 bytes, FETCH uncorrected (MI355X_MICROARCH.md: on gfx950 it reads 1/2 of the bytes of a wide coalesced stream; this kernel's reads are 16-byte gathers, for which the counter is uncalibrated)"}
+for k, r in rows.items():
+    e = {"FETCH_SIZE_KiB": r.get("FETCH_SIZE"), "WRITE_SIZE_KiB": r.get("WRITE_SIZE"),
+         "traffic_bytes": (r.get("FETCH_SIZE", 0) + r.get("WRITE_SIZE", 0)) * 1024.0,
+         "valu_lane_utilisation": r["SQ_THREAD_CYCLES_VALU"] / (r["SQ_ACTIVE_INST_VALU"] * 64.0),
+         "SQ_INSTS_VALU": r["SQ_INSTS_VALU"], "SQ_WAVES": r["SQ_WAVES"],
+         "wait_any_frac": r["SQ_WAIT_ANY"] / r["SQ_WAVE_CYCLES"], "wait_inst_any_frac": r["SQ_WAIT_INST_ANY"] / r["SQ_WAVE_CYCLES"],
+         "gpu_cycles_per_xcd": r["GRBM_GUI_ACTIVE"] / 8.0}
+    if k == "k_path_bwd": e["atomic_requests"] = r.get("TCC_EA0_ATOMIC_sum")
+    out[k] = e
+json.dump(out, open("gpurun_out/${tag}_pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+cp gpurun_out/${tag}_pmc_traffic.json profiles/pmc_traffic.json     # bench.py reads the traffic figure from here
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1 || true
+find gpurun_out/${tag}_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_kernel_stats.csv \;
+timeout -k 10 600 python bench.py --steps 10 --warmup 2 2>gpurun_out/${tag}_bench.err | tail -1 > gpurun_out/${tag}_bench.json
+cat gpurun_out/${tag}_bench.json; head -5 gpurun_out/${tag}_kernel_stats.csv

@@ -96,6 +96,14 @@ ZD float4 read_bsdf(const float4 *__restrict__ mat, f2 uv, int tex_h, int tex_w)
 #define ZDR_SCATTER_CAP 64           // queue entries per wavefront (7 dwords each)
 #endif
 
+// The queue is emptied as soon as it holds ZDR_SCATTER_FLUSH_AT entries (and before it would overflow).  Small
+// bursts matter: a 64-byte atomic occupies the CU's vector-memory path for about 30 cycles
+// (profiles/r1_atomic_rate.txt) and every load of every wave of the CU queues behind the burst.
+#ifndef ZDR_SCATTER_FLUSH_AT
+#define ZDR_SCATTER_FLUSH_AT ZDR_SCATTER_CAP
+#endif
+static_assert(ZDR_SCATTER_CAP >= 64, "one push can add an entry per lane");
+
 struct ScatterQueue {                // pointers into this wave's LDS block
     int *cell; float *g; float *ox; float *oy;
     int count;                       // wave-uniform
@@ -147,6 +155,7 @@ ZD void scatter_push(ScatterQueue &q, float *__restrict__ cells, bool active, f2
         q.ox[slot] = ox; q.oy[slot] = oy;
     }
     q.count += n;
+    if (q.count >= ZDR_SCATTER_FLUSH_AT) scatter_flush(q, cells);
 }
 
 // ------------------------------------------------------------------------------------ lights

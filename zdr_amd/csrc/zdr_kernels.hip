@@ -299,9 +299,6 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
     ScatterQueue q = scatter_queue_init(lds_q);
     PackedVertex deep[ZDR_MAX_RECORDED_DEPTH];
     int nrec = 0;
-    f3 term_Li = mk3(0.0f);
-    int sw_k = -1;                                          // next vertex the sweep consumes
-    SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
     PrimaryQueue pq = queue_init(io);
     f3 unused_sum = mk3(0.0f);
     bool alive = false; int pix = 0;
@@ -342,12 +339,17 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
         if (took >= 0) {
             const int bk = took >> 6, px = took & 63;
             le_grad = mk3(lds_leg[(bk * 3 + 0) * WAVE + px], lds_leg[(bk * 3 + 1) * WAVE + px], lds_leg[(bk * 3 + 2) * WAVE + px]);
-            nrec = 0; term_Li = mk3(0.0f);
+            nrec = 0;
             alive = true; pix = took;
         }
         if (__ballot(alive) != 0ull) {
             progress = true;
             bool done = false;
+            // sweep state: set when a path ends and used up before the trip is over — local to the trip, so that it
+            // holds no registers while the vertex is shaded
+            f3 term_Li = mk3(0.0f);
+            int sw_k = -1;                                  // next vertex the sweep consumes
+            SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
             if (alive) {
                 PathVertex pv; float term_plfrac = 0.0f;
                 done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, cnt);

@@ -32,15 +32,18 @@ ZD uint32_t smear_mask(uint32_t w) { w |= w >> 1; w |= w >> 2; w |= w >> 4; w |=
 // The reference's `while True` never ends for a start value >= l whose cycle stays outside [0, l);
 // a valid walk rejects at most w + 1 - l values, so the loop is bounded by exactly that: every wave
 // is guaranteed to leave it.
+ZD uint32_t kensler_hash(uint32_t i, uint32_t w, uint32_t p) {
+    i ^= p; i *= 0xe170893du; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8;
+    i *= 0x0929eb3fu; i ^= p >> 23; i ^= (i & w) >> 1; i *= 1u | p >> 27;
+    i *= 0x6935fa69u; i ^= (i & w) >> 11; i *= 0x74dcb303u; i ^= (i & w) >> 2;
+    i *= 0x9e501cc3u; i ^= (i & w) >> 2; i *= 0xc860a3dfu; i &= w; i ^= i >> 5;
+    return i;
+}
 ZD uint32_t permutation_element(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
+    if (l == w + 1u) return (kensler_hash(i, w, p) + p) & w;     // wave-uniform: straight-line code, no cycle walk
     uint32_t budget = w - l + 2u;
-    do {
-        i ^= p; i *= 0xe170893du; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8;
-        i *= 0x0929eb3fu; i ^= p >> 23; i ^= (i & w) >> 1; i *= 1u | p >> 27;
-        i *= 0x6935fa69u; i ^= (i & w) >> 11; i *= 0x74dcb303u; i ^= (i & w) >> 2;
-        i *= 0x9e501cc3u; i ^= (i & w) >> 2; i *= 0xc860a3dfu; i &= w; i ^= i >> 5;
-    } while (i >= l && --budget);
-    return (l == w + 1u) ? ((i + p) & w) : ((i + p) % l);
+    do { i = kensler_hash(i, w, p); } while (i >= l && --budget);
+    return (i + p) % l;
 }
 
 // Wave-uniform sampler configuration, computed once per launch on the host.

@@ -150,6 +150,30 @@ def test_tile_masks_cull_nothing_that_can_be_hit(integrator, mat_a, monkeypatch)
             if k == 0: assert float(img[..., :3].sum()) > 0.0
 
 
+@pytest.mark.parametrize("accel", ["brute", "bvh"])
+def test_work_item_granularity_only_reassociates(accel, mat_b, monkeypatch):
+    """The path kernels' persistent waves draw (tile x sample-chunk) items and overlap consecutive items in two LDS
+    banks.  How the samples are cut into items must not matter beyond the order of float additions: one item per
+    tile (a wave finishes a tile before the next), the default, and 4-sample items (every wave juggles many items
+    and both banks all the time) give the same image and gradient."""
+    m = torch.from_numpy(mat_b).cuda()
+    scene = make_scene("path", accel=accel)
+    W, H, spp = 88, 40, 64                                       # 55 tiles, the last column half empty
+    cot = torch.from_numpy(np.random.default_rng(5).uniform(0.5, 1.5, (H, W, 4)).astype(np.float32)).cuda()
+    out = []
+    for env in ({"ZDR_TARGET_WAVES": "1"}, {}, {"ZDR_TARGET_WAVES": "100000", "ZDR_MIN_CHUNK": "4"}):
+        for k in ("ZDR_TARGET_WAVES", "ZDR_MIN_CHUNK"): monkeypatch.delenv(k, raising=False)
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        img = scene.render_forward(m, (W, H), spp, 21)
+        g = torch.zeros_like(m); scene.render_backward(cot, g, m, (W, H), spp, 21)
+        st = scene.render_stats(m, (W, H), spp, 21)
+        out.append((img, g, st))
+    for img, g, st in out[1:]:
+        torch.testing.assert_close(img, out[0][0], rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(g, out[0][1], rtol=1e-4, atol=1e-6 * float(out[0][1].abs().max()))
+        assert st == out[0][2]                                   # the very same paths: identical counters
+
+
 def test_stats_match_oracle_counters(cbox_oracle, mat_a):
     scene = make_scene("path")
     m = torch.from_numpy(mat_a).cuda()

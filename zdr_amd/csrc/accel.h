@@ -146,13 +146,18 @@ struct BvhAccel {
     static constexpr bool kNeedsLds = true;
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
     // 4-wide BVH, one 128-byte node per visit (8 dwordx4 loads of one line), nearest hit child first.
-    // stack: this wave's LDS region, ZDR_BVH_STACK x 64 ints; entry e of lane l at stack[e * 64 + l].
+    // stack: this wave's LDS region, min(S.stack_entries, ZDR_BVH_LDS_STACK) x 64 ints; entry e of lane l at stack[e * 64 + l].
     // A work item is (id, cnt): cnt == 0 -> node id, cnt > 0 -> leaf slots [id, id + cnt); cnt < 0 -> unused child.
     template <bool ANY>
     ZD static Hit traverse(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
         const int lane = threadIdx.x & 63;
         f3 inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+        // Entries [0, LN) of the stack live in LDS, deeper ones in per-lane scratch: the builder's bound
+        // (up to 44 entries on a 1 M triangle tree, 11 KiB of LDS per wave) is a worst case that real rays
+        // almost never approach, and LDS is what limits the waves per CU of the BVH kernels.
+        const int LN = (S.stack_entries < ZDR_BVH_LDS_STACK) ? S.stack_entries : ZDR_BVH_LDS_STACK;
+        int deep[ZDR_BVH_STACK - ZDR_BVH_LDS_STACK + 4];
         int sp = 0;
         int id = 0, cnt = (S.nnodes == 0) ? S.ntris : 0;
         // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it
@@ -179,12 +184,24 @@ struct BvhAccel {
                 if (em < 2.0e38f) {
                     bool t0 = (e0 == em), t1 = !t0 & (e1 == em), t2 = !(t0 | t1) & (e2 == em), t3 = !(t0 | t1 | t2);
                     int next = t0 ? p0 : (t1 ? p1 : (t2 ? p2 : p3));
-                    int *sl = stack + sp * 64 + lane;
-                    sl[0] = p0; sl += (!t0 & (e0 < 2.0e38f)) ? 64 : 0;
-                    sl[0] = p1; sl += (!t1 & (e1 < 2.0e38f)) ? 64 : 0;
-                    sl[0] = p2; sl += (!t2 & (e2 < 2.0e38f)) ? 64 : 0;
-                    sl[0] = p3; sl += (!t3 & (e3 < 2.0e38f)) ? 64 : 0;
-                    sp = (int)((sl - (stack + lane)) >> 6);
+                    if (sp + 4 <= LN) {
+                        int *sl = stack + sp * 64 + lane;
+                        sl[0] = p0; sl += (!t0 & (e0 < 2.0e38f)) ? 64 : 0;
+                        sl[0] = p1; sl += (!t1 & (e1 < 2.0e38f)) ? 64 : 0;
+                        sl[0] = p2; sl += (!t2 & (e2 < 2.0e38f)) ? 64 : 0;
+                        sl[0] = p3; sl += (!t3 & (e3 < 2.0e38f)) ? 64 : 0;
+                        sp = (int)((sl - (stack + lane)) >> 6);
+                    } else {                                // near or past the LDS part: one entry at a time
+                        const int pp[4] = {p0, p1, p2, p3};
+                        const bool keep[4] = {!t0 && e0 < 2.0e38f, !t1 && e1 < 2.0e38f, !t2 && e2 < 2.0e38f, !t3 && e3 < 2.0e38f};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (keep[j]) {
+                                if (sp < LN) stack[sp * 64 + lane] = pp[j]; else deep[sp - LN] = pp[j];
+                                sp++;
+                            }
+                        }
+                    }
                     id = next >> 3; cnt = next & 7;
                     continue;
                 }
@@ -198,7 +215,7 @@ struct BvhAccel {
             }
             if (sp == 0) break;
             sp--;
-            int e = stack[sp * 64 + lane];
+            int e = (sp < LN) ? stack[sp * 64 + lane] : deep[sp - LN];
             id = e >> 3; cnt = e & 7;
         }
         if (!ANY) hit_barycentrics(S, h, o, d);

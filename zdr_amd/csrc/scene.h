@@ -5,6 +5,9 @@
 #include "vecmath.h"
 
 #define ZDR_BVH_STACK 48   // upper bound of per-lane traversal stack entries; the builder bounds the tree depth below it
+#ifndef ZDR_BVH_LDS_STACK
+#define ZDR_BVH_LDS_STACK 8    // of which this many live in LDS (the rest, rarely reached, in scratch); 1 M triangles, fwd / bwd ms: 44 (all) 94 / 149, 16: 92 / 115, 12: 91 / 115, 8: 93 / 108
+#endif
 
 // Per-slot records, 16-byte aligned so a record is fetched with dwordx4 loads:
 //   isect[3*slot + {0,1,2}] = {n, n.p0} {nu, du} {nv, dv}              (48 B, plane-form triangle test)
@@ -29,7 +32,7 @@ struct DScene {
     // environment light (envmap.py; heap slots 23330-23332): lat-long RGBA texture + importance tables
     const float4 *env_tex; const float *alias_prob; const int32_t *alias_idx; const float *env_pdf;
     int32_t env_count, env_h, env_w, map_w, map_h;
-    int32_t stack_entries;          // per-lane traversal stack entries this tree needs (dynamic LDS: entries x 64 ints per wave)
+    int32_t stack_entries;          // per-lane traversal stack entries this tree needs (dynamic LDS: min(entries, ZDR_BVH_LDS_STACK) x 64 ints per wave)
 };
 
 struct Hit { int slot; float u, v, t; };   // slot < 0: miss (LuisaCompute Hit{inst, prim, bary, ray_t})

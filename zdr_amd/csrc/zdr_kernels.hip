@@ -167,7 +167,7 @@ struct ItemBanks {
 
 template <int SK, class A, bool STATS, bool ENV>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
-    extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
+    extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ uint32_t lds_perm[2 * WAVE];
     __shared__ int lds_origin[4];
     __shared__ float lds_sum[2 * 3 * WAVE];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCf
 #endif
 template <int SK, class A, bool ENV>
 __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
-    extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
+    extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
     __shared__ float4 lds_rec[ZDR_LDS_VERTICES * 4 * WAVE];
     __shared__ float lds_dlnp[ZDR_LDS_VERTICES * WAVE];
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, 
 // ---------------------------------------------------------------------- direct / collocated
 template <int INTEG, int SK, class A, bool BWD, bool STATS, bool ENV>
 __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
-    extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
+    extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 1];
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
@@ -558,7 +558,7 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
     if (nblocks <= 0) return 0;
     dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
-    const size_t dyn = accel_is_bvh ? (size_t)S.stack_entries * WAVE * sizeof(int) : 0;
+    const size_t dyn = accel_is_bvh ? (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int) : 0;
     if (io.tile_masks)
         hipLaunchKernelGGL(k_tile_masks, dim3(R.tiles_x * R.tiles_y), dim3(WAVE), 0, st, S, R, (unsigned long long *)io.tile_masks);
     if (C.kind == ZDR_SAMPLER_CMJ) {
@@ -582,7 +582,7 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
 // ------------------------------------------------------------------------- ray batch queries
 template <class A, bool ANY>
 __global__ __launch_bounds__(WAVE) void k_trace(DScene S, const float4 *rays, uint32_t n, int32_t *out_i, float *out_f) {
-    extern __shared__ int lds[];        // BvhAccel: stack_entries x 64 ints (sized at launch); unused otherwise
+    extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     bool valid = i < n;
     float4 a = valid ? rays[2 * (size_t)i] : make_float4(0, 0, 0, 0), b = valid ? rays[2 * (size_t)i + 1] : make_float4(0, 0, 1, 0);
@@ -605,7 +605,7 @@ int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *ra
     dim3 grid((n + WAVE - 1) / WAVE);
     const float4 *r = (const float4 *)rays;
     if (accel_is_bvh) {
-        const size_t dyn = (size_t)S.stack_entries * WAVE * sizeof(int);
+        const size_t dyn = (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int);
         if (any) hipLaunchKernelGGL((k_trace<BvhAccel, true>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
         else hipLaunchKernelGGL((k_trace<BvhAccel, false>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
     } else {

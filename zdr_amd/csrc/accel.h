@@ -8,6 +8,14 @@
 #pragma once
 #include "scene.h"
 
+// __launch_bounds__ second argument of the path kernels = minimum waves per SIMD (caps the VGPR budget at 512 / n)
+#ifndef ZDR_MIN_WAVES
+#define ZDR_MIN_WAVES 3
+#endif
+#ifndef ZDR_MIN_WAVES_BVH
+#define ZDR_MIN_WAVES_BVH 5
+#endif
+
 #ifndef ZDR_TRI_UNROLL
 #define ZDR_TRI_UNROLL 1
 #endif
@@ -83,6 +91,7 @@ ZD PairHit pair_test(const_v4f_ptr q, f3 o, f3 d) {
 
 struct BruteAccel {
     static constexpr bool kNeedsLds = false;
+    static constexpr int kMinWavesFwd = ZDR_MIN_WAVES;       // issue-bound: more waves per SIMD buy nothing
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
         const_v4f_ptr q = as_constant(S.pairs);
@@ -144,6 +153,7 @@ ZD float box_entry(float lox, float loy, float loz, float hix, float hiy, float 
 
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
+    static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // latency-bound: 5 waves per SIMD (<= 102 VGPRs, a few spills) is 15 % faster than 3 on 1 M triangles
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
     // 4-wide BVH, one 128-byte node per visit (8 dwordx4 loads of one line), nearest hit child first.
     // stack: this wave's LDS region, min(S.stack_entries, ZDR_BVH_LDS_STACK) x 64 ints; entry e of lane l at stack[e * 64 + l].

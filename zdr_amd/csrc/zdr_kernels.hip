@@ -13,9 +13,6 @@
 #define WAVE 64
 // __launch_bounds__ second argument = minimum waves per SIMD (caps the VGPR budget at 512 / n).
 // Measured on cbox 512^2 spp 256 (profiles/r1_ab_flags.txt): 3 (<= 168 VGPRs, no spills) is best for both.
-#ifndef ZDR_MIN_WAVES
-#define ZDR_MIN_WAVES 3
-#endif
 #ifndef ZDR_MIN_WAVES_BWD
 #define ZDR_MIN_WAVES_BWD ZDR_MIN_WAVES
 #endif
@@ -166,7 +163,7 @@ struct ItemBanks {
 };
 
 template <int SK, class A, bool STATS, bool ENV>
-__global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, A::kMinWavesFwd) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ uint32_t lds_perm[2 * WAVE];
     __shared__ int lds_origin[4];

@@ -542,7 +542,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
 
 static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
     if (R.nchunks <= 1) return ZDR_OK;
-    size_t need = (size_t)R.nchunks * R.width * R.height * sizeof(float4);
+    size_t need = (size_t)R.nchunks * (size_t)(R.x1 - R.x0) * (size_t)(R.y1 - R.y0) * sizeof(float4);   // the shard rectangle only
     if (need > s->partial_bytes) {
         (void)hipFree(s->d_partial); s->d_partial = nullptr; s->partial_bytes = 0;
         HIPCHK(hipMalloc((void **)&s->d_partial, need));

@@ -81,7 +81,9 @@ ZD void store_pixel(const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
         float fs = (float)C.spp;
         io.image[w.pix] = make_float4(__fdiv_rn(sum.x, fs), __fdiv_rn(sum.y, fs), __fdiv_rn(sum.z, fs), R.alpha);
     } else {
-        io.partial[(size_t)w.chunk * ((size_t)R.width * R.height) + w.pix] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        // chunk partials cover the shard rectangle only: [chunk][y - y0][x - x0]
+        const size_t rw = (size_t)(R.x1 - R.x0), rh = (size_t)(R.y1 - R.y0);
+        io.partial[(size_t)w.chunk * (rw * rh) + (size_t)(w.y - R.y0) * rw + (size_t)(w.x - R.x0)] = make_float4(sum.x, sum.y, sum.z, 0.0f);
     }
 }
 
@@ -493,9 +495,10 @@ __global__ __launch_bounds__(WAVE) void k_uvgrad(DScene S, RenderCfg R, SamplerC
 __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial, float4 *image) {
     int x = R.x0 + blockIdx.x * blockDim.x + threadIdx.x, y = R.y0 + blockIdx.y;
     if (x >= R.x1 || y >= R.y1) return;
-    size_t pix = (size_t)x + (size_t)y * R.width, npix = (size_t)R.width * R.height;
+    const size_t pix = (size_t)x + (size_t)y * R.width;
+    const size_t rw = (size_t)(R.x1 - R.x0), npix = rw * (size_t)(R.y1 - R.y0), rpix = (size_t)(y - R.y0) * rw + (size_t)(x - R.x0);
     f3 s = mk3(0.0f);
-    for (int c = 0; c < R.nchunks; c++) { float4 p = partial[(size_t)c * npix + pix]; s = s + mk3(p.x, p.y, p.z); }
+    for (int c = 0; c < R.nchunks; c++) { float4 p = partial[(size_t)c * npix + rpix]; s = s + mk3(p.x, p.y, p.z); }
     float fs = (float)spp;
     image[pix] = make_float4(__fdiv_rn(s.x, fs), __fdiv_rn(s.y, fs), __fdiv_rn(s.z, fs), R.alpha);
 }

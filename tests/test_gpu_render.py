@@ -150,6 +150,34 @@ def test_tile_masks_cull_nothing_that_can_be_hit(integrator, mat_a, monkeypatch)
             if k == 0: assert float(img[..., :3].sum()) > 0.0
 
 
+@pytest.mark.parametrize("W,H,spp,max_depth,rr_depth", [
+    (1, 1, 1, 16, 2),        # one pixel, one sample: a wave with one valid lane and a one-entry FIFO
+    (5, 3, 3, 16, 2),        # fewer camera samples than one refill batch
+    (24, 16, 32, 1, 2),      # max_depth 1: every path stops after its first vertex
+    (24, 16, 32, 16, 0),     # Russian roulette from the first vertex: no vertex record lives in LDS
+    (24, 16, 32, 16, 16),    # no Russian roulette: paths run to max_depth, 14 records per lane in scratch
+    (24, 16, 32, 3, 1),
+])
+def test_edge_configurations_match_oracle(W, H, spp, max_depth, rr_depth, cbox_oracle, cbox_oracle_fma, mat_a):
+    """Path forward + backward at the corners of the configuration space of prb.py:15-16 and of the
+    persistent kernels' machinery (tiny shards, tiny sample counts, depth limits).  Material A (rough):
+    with a few dozen pixels the floor-calibrated statistics of a glossy material mean nothing."""
+    m = torch.from_numpy(mat_a).cuda()
+    scene = make_scene("path")
+    scene.max_depth, scene.rr_depth = max_depth, rr_depth
+    p = oracle_params(scene, W, H, spp, 77, mat_a.shape[:2])
+    img = scene.render_forward(m, (W, H), spp, 77).cpu().numpy()
+    ref = cbox_oracle.render_forward(p, mat_a)
+    tag = f"path {W}x{H} spp{spp} depth{max_depth}/{rr_depth}"
+    assert_image_parity(img[..., :3], ref[..., :3], tag)
+    cot = np.random.default_rng(3).uniform(0.5, 1.5, (H, W, 4)).astype(np.float32)
+    g = torch.zeros_like(m)
+    scene.render_backward(torch.from_numpy(cot).cuda(), g, m, (W, H), spp, 77)
+    pb = oracle_params(scene, W, H, spp, 78, mat_a.shape[:2])    # backward renders with seed + 1 (render.py:196)
+    assert_grad_parity(g.cpu().numpy(), cbox_oracle.render_backward(pb, cot, mat_a), tag + " backward",
+                       floor=cbox_oracle_fma.render_backward(pb, cot, mat_a))   # 16-vertex paths accumulate rounding
+
+
 @pytest.mark.parametrize("accel", ["brute", "bvh"])
 def test_work_item_granularity_only_reassociates(accel, mat_b, monkeypatch):
     """The path kernels' persistent waves draw (tile x sample-chunk) items and overlap consecutive items in two LDS

@@ -7,6 +7,9 @@
 // run of tiles: primary-hit texel footprints of neighbouring tiles then share that XCD's L2.
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include "integrators.h"
 #include "zdr.h"
 
@@ -509,10 +512,21 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 template <class K>
 static dim3 persistent_grid(K kernel, size_t dyn, int nitems) {
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, dyn) != hipSuccess || per_cu < 1) per_cu = 8;
-    if (const char *e = getenv("ZDR_PERSISTENT_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
     (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    {   // the occupancy query costs tens of microseconds: remember it per (kernel, dynamic LDS, device)
+        static std::mutex mu;
+        static std::map<std::tuple<const void *, size_t, int>, std::pair<int, int>> cache;
+        std::lock_guard<std::mutex> lock(mu);
+        auto key = std::make_tuple((const void *)kernel, dyn, dev);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, dyn) != hipSuccess || per_cu < 1) per_cu = 8;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            it = cache.emplace(key, std::make_pair(per_cu, cus)).first;
+        }
+        per_cu = it->second.first; cus = it->second.second;
+    }
+    if (const char *e = getenv("ZDR_PERSISTENT_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));
     long g = std::min<long>((long)per_cu * cus, (long)ZDR_MAX_PERSISTENT_BLOCKS);
     return dim3((unsigned)std::max<long>(1, std::min<long>(g, nitems)));
 }

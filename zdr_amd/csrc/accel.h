@@ -15,6 +15,19 @@
 #ifndef ZDR_MIN_WAVES_BVH
 #define ZDR_MIN_WAVES_BVH 5
 #endif
+#ifndef ZDR_MIN_WAVES_BWD
+#define ZDR_MIN_WAVES_BWD ZDR_MIN_WAVES
+#endif
+#ifndef ZDR_MIN_WAVES_BWD_BVH
+#define ZDR_MIN_WAVES_BWD_BVH 4
+#endif
+// vertex records of the backward kernel kept in LDS (4.25 KiB per wave each)
+#ifndef ZDR_LDS_VERTICES
+#define ZDR_LDS_VERTICES 2
+#endif
+#ifndef ZDR_LDS_VERTICES_BVH
+#define ZDR_LDS_VERTICES_BVH 1
+#endif
 
 #ifndef ZDR_TRI_UNROLL
 #define ZDR_TRI_UNROLL 1
@@ -92,6 +105,8 @@ ZD PairHit pair_test(const_v4f_ptr q, f3 o, f3 d) {
 struct BruteAccel {
     static constexpr bool kNeedsLds = false;
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES;       // issue-bound: more waves per SIMD buy nothing
+    static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD;
+    static constexpr int kLdsVertices = ZDR_LDS_VERTICES;    // scratch records thrash L2 on cbox (1 instead of 2: 16.7 -> 19.0 ms)
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
         const_v4f_ptr q = as_constant(S.pairs);
@@ -154,6 +169,8 @@ ZD float box_entry(float lox, float loy, float loz, float hix, float hiy, float 
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // latency-bound: 5 waves per SIMD (<= 102 VGPRs, a few spills) is 15 % faster than 3 on 1 M triangles
+    static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
+    static constexpr int kLdsVertices = ZDR_LDS_VERTICES_BVH;    // <= 128 VGPRs give 15 waves per CU instead of 11 (109 -> 94 ms on 1 M triangles)
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
     // 4-wide BVH, one 128-byte node per visit (8 dwordx4 loads of one line), nearest hit child first.
     // stack: this wave's LDS region, min(S.stack_entries, ZDR_BVH_LDS_STACK) x 64 ints; entry e of lane l at stack[e * 64 + l].

@@ -16,9 +16,6 @@
 #define WAVE 64
 // __launch_bounds__ second argument = minimum waves per SIMD (caps the VGPR budget at 512 / n).
 // Measured on cbox 512^2 spp 256 (profiles/r1_ab_flags.txt): 3 (<= 168 VGPRs, no spills) is best for both.
-#ifndef ZDR_MIN_WAVES_BWD
-#define ZDR_MIN_WAVES_BWD ZDR_MIN_WAVES
-#endif
 
 struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk, tile; };
 
@@ -276,20 +273,18 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesFwd) void k_path(DScene S, Render
 // gradients; all queue traffic happens at reconverged points so the whole wave takes part in a flush.
 // Keeping the records out of scratch is what matters: 2.3 KB of scratch per lane thrashed L2 (113 GB of
 // fabric traffic per launch, 13 of 37 ms).
-#ifndef ZDR_LDS_VERTICES
-#define ZDR_LDS_VERTICES 2
-#endif
 template <int SK, class A, bool ENV>
-__global__ __launch_bounds__(WAVE, ZDR_MIN_WAVES_BWD) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
-    __shared__ float4 lds_rec[ZDR_LDS_VERTICES * 4 * WAVE];
-    __shared__ float lds_dlnp[ZDR_LDS_VERTICES * WAVE];
+    constexpr int LV = A::kLdsVertices;                     // vertex records kept in LDS (the others go to scratch)
+    __shared__ float4 lds_rec[LV * 4 * WAVE];
+    __shared__ float lds_dlnp[LV * WAVE];
     __shared__ uint32_t lds_perm[2 * WAVE];                 // per item bank (see k_path): CMJ seeds, tile origin,
     __shared__ int lds_origin[4];
     __shared__ float lds_leg[2 * 3 * WAVE];                 // and the pixel cotangents / spp
     const int lane = threadIdx.x;
-    const int lds_vertices = (R.rr_depth < ZDR_LDS_VERTICES) ? max(R.rr_depth, 0) : ZDR_LDS_VERTICES;   // LDS records carry no RR fields
+    const int lds_vertices = (R.rr_depth < LV) ? max(R.rr_depth, 0) : LV;   // LDS records carry no RR fields
     Counters cnt;
     ItemBanks ib; ib.logical[0] = ib.logical[1] = -1; ib.inflight[0] = ib.inflight[1] = 0;
     int bank = 1;

@@ -134,7 +134,7 @@ int zdr_sampler_dump(zdr_scene *scene, int32_t sampler, uint32_t seed, uint32_t 
 /* Host-only: builds the acceleration structure exactly as zdr_scene_create does and returns it,
  * without touching a GPU, so that the CPU test-suite can run an emulation of the device traversal
  * on the very data the kernels read (tests/test_bvh_emulation.py).  tri_xyz: ntris x 9 world-space
- * corners.  nodes_out: nodes_cap x 32 floats (BVH4 node = 128 bytes, layout in csrc/scene.h);
+ * corners.  nodes_out: nodes_cap x 16 floats (BVH4 node = 64 bytes, layout in csrc/scene.h);
  * order_out[slot] = input triangle; isect_out: ntris x 12 floats (plane-form records, slot order). */
 int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int accel, float *nodes_out, uint32_t nodes_cap,
                           uint32_t *nnodes, uint32_t *stack_entries, int32_t *order_out, float *isect_out);

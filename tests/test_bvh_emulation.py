@@ -27,7 +27,7 @@ def world_triangles(A):
 def build(A, accel):
     tri = np.ascontiguousarray(world_triangles(A).reshape(-1, 9))
     n = tri.shape[0]
-    nodes = np.zeros((max(n, 8), 32), np.float32)
+    nodes = np.zeros((max(n, 8), 16), np.float32)      # BVH4 node = 64 bytes (csrc/scene.h)
     order = np.zeros(n, np.int32); isect = np.zeros((n, 12), np.float32); nn = C.c_uint32(); se = C.c_uint32()
     rc = _native.lib().zdr_debug_build_accel(tri.ctypes.data, n, accel, nodes.ctypes.data, nodes.shape[0], C.byref(nn), C.byref(se), order.ctypes.data, isect.ctypes.data)
     assert rc == 0, _native.lib().zdr_last_error()
@@ -48,12 +48,26 @@ def tri_test(q, o, d, tmin, tmax):
     return bool(t > tmin and t < tmax and u >= 0 and v >= 0 and u + v <= 1), t
 
 
-def box_entry(lo, hi, o, inv, tmin, tmax):
+def qbox_entry(k, q, A, B, tmin, tmax):
+    """mirror of qbox_entry<K>: q = (lxq, lyq, lzq, hxq, hyq, hzq) words, byte k belongs to child k; t = q A + B in float32"""
+    f = np.float32
+    ql = np.array([(int(q[a]) >> (8 * k)) & 255 for a in range(3)], np.float32)
+    qh = np.array([(int(q[3 + a]) >> (8 * k)) & 255 for a in range(3)], np.float32)
     with np.errstate(invalid="ignore", over="ignore"):
-        t0 = (lo - o) * inv; t1 = (hi - o) * inv
+        # fmaf: one rounding; float64 product + sum rounded once is exact enough to mirror it (24 x 8 bit product is exact)
+        t0 = (ql.astype(np.float64) * A.astype(np.float64) + B.astype(np.float64)).astype(f)
+        t1 = (qh.astype(np.float64) * A.astype(np.float64) + B.astype(np.float64)).astype(f)
     tn = max(np.fmax.reduce(np.fmin(t0, t1)), tmin)      # fmin/fmax drop NaNs like v_min_f32 / v_max_f32
     tf = min(np.fmin.reduce(np.fmax(t0, t1)), tmax)
     return tn if tn <= tf else 3.0e38
+
+
+def decode_node(n):
+    """{origin.xyz, scale.x} {scale.y, scale.z, qlo.x, qlo.y} {qlo.z, qhi.x, qhi.y, qhi.z} {child words}"""
+    w = n.view(np.uint32)
+    origin = n[0:3].copy(); scale = np.array([n[3], n[4], n[5]], np.float32)
+    q = [w[6], w[7], w[8], w[9], w[10], w[11]]
+    return origin, scale, q, [int(x) for x in w[12:16]]
 
 
 def traverse(nodes, isect, o, d, tmin, tmax, any_hit):
@@ -73,11 +87,10 @@ def traverse(nodes, isect, o, d, tmin, tmax, any_hit):
         steps += 1
         descended = False
         if cnt == 0:
-            n = nodes[nid]
-            lo = np.stack([n[0:4], n[4:8], n[8:12]], 1); hi = np.stack([n[12:16], n[16:20], n[20:24]], 1)
-            child = n[24:28].view(np.int32); k = n[28:32].view(np.int32)
-            e = [box_entry(lo[c], hi[c], o, inv, tmin, best_t) if k[c] >= 0 else 3.0e38 for c in range(4)]
-            p = [(int(child[c]) << 3) | int(k[c]) for c in range(4)]
+            origin, scale, q, p = decode_node(nodes[nid])
+            with np.errstate(invalid="ignore", over="ignore"):
+                A = (scale * inv).astype(np.float32); B = ((origin - o) * inv).astype(np.float32)
+            e = [qbox_entry(c, q, A, B, tmin, best_t) if (p[c] & 7) != 7 else 3.0e38 for c in range(4)]
             em = min(e)
             if em < 2.0e38:
                 nxt, taken = -1, [False] * 4

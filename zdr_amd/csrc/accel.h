@@ -1,8 +1,8 @@
 // accel.h — closest-hit / any-hit queries (LuisaCompute Accel.trace_closest / trace_any).
 //  * BruteAccel: for scenes of a few dozen triangles (cbox: 32).  The slot loop is wave-uniform,
 //    so triangle data arrives through scalar loads into SGPRs and costs no VGPRs or LDS.
-//  * BvhAccel: BVH2 with a per-lane traversal stack in LDS laid out [entry][lane] (one bank per
-//    lane, conflict-free), 64-byte nodes and 48-byte triangles fetched with dwordx4 loads.
+//  * BvhAccel: BVH4 with 64-byte quantised nodes, a per-lane traversal stack (first entries in LDS laid out
+//    [entry][lane], one bank per lane; the rest in scratch) and 48-byte triangles fetched with dwordx4 loads.
 // Both run the same two-sided plane-form triangle test accepting tmin < t < tmax, so they return
 // the same hit (up to exact ties in t).
 #pragma once
@@ -155,12 +155,16 @@ struct BruteAccel {
     }
 };
 
-// slab test against one child box; returns entry distance, or 3e38 on a miss
-ZD float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv, float tmin, float tmax) {
-    float t0x = (lox - o.x) * inv.x, t1x = (hix - o.x) * inv.x;
-    float t0y = (loy - o.y) * inv.y, t1y = (hiy - o.y) * inv.y;
-    float t0z = (loz - o.z) * inv.z, t1z = (hiz - o.z) * inv.z;
-    // fminf/fmaxf drop NaNs (0 * inf on a slab boundary), which keeps the test conservative
+// slab test against child K of a quantised node (byte K of each q word); returns the entry distance, or 3e38 on a miss.
+// fminf/fmaxf drop NaNs (0 * inf when a direction component is 0), which keeps the test conservative.
+template <int K> ZD float ubyte(uint32_t w) {
+    return (float)((w >> (8 * K)) & 0xffu);              // v_cvt_f32_ubyteK
+}
+template <int K>
+ZD float qbox_entry(uint32_t lxq, uint32_t lyq, uint32_t lzq, uint32_t hxq, uint32_t hyq, uint32_t hzq, f3 A, f3 B, float tmin, float tmax) {
+    float t0x = fmaf(ubyte<K>(lxq), A.x, B.x), t1x = fmaf(ubyte<K>(hxq), A.x, B.x);
+    float t0y = fmaf(ubyte<K>(lyq), A.y, B.y), t1y = fmaf(ubyte<K>(hyq), A.y, B.y);
+    float t0z = fmaf(ubyte<K>(lzq), A.z, B.z), t1z = fmaf(ubyte<K>(hzq), A.z, B.z);
     float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
     float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
     return (tn <= tf) ? tn : 3.0e38f;
@@ -172,9 +176,9 @@ struct BvhAccel {
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES_BVH;    // <= 128 VGPRs give 15 waves per CU instead of 11 (109 -> 94 ms on 1 M triangles)
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
-    // 4-wide BVH, one 128-byte node per visit (8 dwordx4 loads of one line), nearest hit child first.
+    // 4-wide BVH, one 64-byte quantised node per visit (4 dwordx4 loads), nearest hit child first.
     // stack: this wave's LDS region, min(S.stack_entries, ZDR_BVH_LDS_STACK) x 64 ints; entry e of lane l at stack[e * 64 + l].
-    // A work item is (id, cnt): cnt == 0 -> node id, cnt > 0 -> leaf slots [id, id + cnt); cnt < 0 -> unused child.
+    // A work item is (id, cnt): cnt == 0 -> node id, 1..4 -> leaf slots [id, id + cnt); 7 marks an unused child and is never pushed.
     template <bool ANY>
     ZD static Hit traverse(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
@@ -193,17 +197,20 @@ struct BvhAccel {
         for (;;) {
             if (--budget < 0) break;
             if (cnt == 0) {
-                const float4 *n = S.nodes + 8 * (size_t)id;
-                float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], ci = n[6], ck = n[7];
-                int k0 = __float_as_int(ck.x), k1 = __float_as_int(ck.y), k2 = __float_as_int(ck.z), k3 = __float_as_int(ck.w);
-                // cnt < 0 marks an unused child slot (a slab test cannot express "never hit": it takes
-                // min/max of the two plane distances, so an inverted box still passes)
-                float e0 = (k0 >= 0) ? box_entry(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, o, inv, tmin, h.t) : 3.0e38f;
-                float e1 = (k1 >= 0) ? box_entry(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, o, inv, tmin, h.t) : 3.0e38f;
-                float e2 = (k2 >= 0) ? box_entry(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, o, inv, tmin, h.t) : 3.0e38f;
-                float e3 = (k3 >= 0) ? box_entry(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, o, inv, tmin, h.t) : 3.0e38f;
-                int p0 = (__float_as_int(ci.x) << 3) | k0, p1 = (__float_as_int(ci.y) << 3) | k1;
-                int p2 = (__float_as_int(ci.z) << 3) | k2, p3 = (__float_as_int(ci.w) << 3) | k3;
+                const float4 *n = S.nodes + 4 * (size_t)id;
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                // slab distances on the node's quantisation grid: t = (origin + scale q - o) / d = q A + B
+                const f3 A = mk3(n0.w * inv.x, n1.x * inv.y, n1.y * inv.z);
+                const f3 B = mk3((n0.x - o.x) * inv.x, (n0.y - o.y) * inv.y, (n0.z - o.z) * inv.z);
+                const uint32_t lxq = __float_as_uint(n1.z), lyq = __float_as_uint(n1.w), lzq = __float_as_uint(n2.x);
+                const uint32_t hxq = __float_as_uint(n2.y), hyq = __float_as_uint(n2.z), hzq = __float_as_uint(n2.w);
+                const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), c2 = __float_as_uint(n3.z), c3 = __float_as_uint(n3.w);
+                // count == 7 marks an unused child slot (a slab test cannot express "never hit")
+                float e0 = ((c0 & 7u) != 7u) ? qbox_entry<0>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
+                float e1 = ((c1 & 7u) != 7u) ? qbox_entry<1>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
+                float e2 = ((c2 & 7u) != 7u) ? qbox_entry<2>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
+                float e3 = ((c3 & 7u) != 7u) ? qbox_entry<3>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
+                int p0 = (int)c0, p1 = (int)c1, p2 = (int)c2, p3 = (int)c3;
                 // nearest child: visit now; the other hit children go on the stack.  The four stack
                 // writes are unconditional (LDS stores are cheap, branches are not): a slot is kept only
                 // if sp advances past it.  The builder guarantees sp + 4 <= ZDR_BVH_STACK here.

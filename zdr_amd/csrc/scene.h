@@ -16,9 +16,10 @@
 //     r3 {n0.xyz, uv1.y} r4 {n1.xyz, uv2.x} r5 {n2.xyz, uv2.y}   n_i = inverse-transpose(M) * vn_i
 //     r6 {ng.xyz, area}                                          ng = normalize(cross(p1-p0, p2-p0))
 //     r7 {bits(inst), bits(prim), 0, 0}
-// BVH4 node (128 B, one line): {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]} {child[4]} {cnt[4]}
-//   cnt == 0: child is a node index; cnt > 0: child is the first slot of a leaf of cnt triangles;
-//   an unused child has an inverted box.
+// BVH4 node (64 B, four float4; child boxes quantised to 8 bits per plane on the node's own grid, rounded outwards):
+//   {origin.xyz, scale.x} {scale.y, scale.z, qlo.x[4], qlo.y[4]} {qlo.z[4], qhi.x[4], qhi.y[4], qhi.z[4]} {child[4]}
+//   plane = origin + scale * q (byte k of a q word belongs to child k); child = index << 3 | count:
+//   count == 0: index is a node; 1..4: first slot of a leaf of `count` triangles; 7: unused child.
 struct DScene {
     const float4 *isect;
     const float4 *pairs;            // brute-force accel only: isect records of slots (2k, 2k+1) interleaved, 6 float4 per pair (accel.h)

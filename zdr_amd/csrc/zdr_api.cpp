@@ -158,16 +158,19 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
     float diag = sqrtf((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
     float pad = 4e-6f * diag + 1e-30f;
     // Collapse to a 4-wide BVH: a node adopts its grandchildren (largest box first) until it has
-    // four children or only leaves.  One node = one 128-byte line, SoA child boxes:
-    //   {lo.x[4]} {lo.y[4]} {lo.z[4]} {hi.x[4]} {hi.y[4]} {hi.z[4]} {child[4]} {count[4]}
-    // count == 0: child is a node index; count > 0: child is the first slot of a leaf; an unused
-    // child has an inverted box (never hit).  Node 0 is the root; a scene that is one leaf has no nodes.
+    // four children or only leaves.  One node = 64 bytes (four dwordx4 loads per visit — the BVH kernels are
+    // bound by the number of per-lane vector loads, so bytes per visit is what counts): the child boxes are
+    // quantised to 8 bits per plane on the node's own grid,
+    //   {origin.xyz, scale.x} {scale.y, scale.z, qlo.x[4], qlo.y[4]} {qlo.z[4], qhi.x[4], qhi.y[4], qhi.z[4]} {child[4]}
+    // plane = origin + scale * q, rounded outwards (a quantised box always contains the padded float box);
+    // child = index << 3 | count: count 0 = node index, 1..4 = first slot of a leaf, 7 = unused child.
+    // Node 0 is the root; a scene that is one leaf has no nodes.
     int ninner = 0, worst_stack = 0;
     if (bb.nodes[0].count == 0) {
         struct Item { int bnode, id4, stack; };
         std::vector<Item> todo; todo.push_back({0, 0, 0});
         ninner = 1;
-        nodes.assign(8, make_float4(0, 0, 0, 0));
+        nodes.assign(4, make_float4(0, 0, 0, 0));
         while (!todo.empty()) {
             Item it = todo.back(); todo.pop_back();
             int kids[4], nk = 2;
@@ -190,7 +193,7 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
                     if (n.count) { child[k] = n.first; cnt[k] = n.count; }
                     else {
                         child[k] = ninner++; cnt[k] = 0;
-                        nodes.resize(8 * (size_t)ninner, make_float4(0, 0, 0, 0));
+                        nodes.resize(4 * (size_t)ninner, make_float4(0, 0, 0, 0));
                         todo.push_back({kids[k], child[k], it.stack + nk - 1});
                     }
                 } else {
@@ -199,13 +202,34 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
                 }
             }
             worst_stack = std::max(worst_stack, it.stack + nk - 1);
-            float4 *o = &nodes[8 * (size_t)it.id4];
+            // quantise on the node's grid
+            float org[3], scl[3]; uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
             for (int ax = 0; ax < 3; ax++) {
-                o[ax] = make_float4(lo[ax][0], lo[ax][1], lo[ax][2], lo[ax][3]);
-                o[3 + ax] = make_float4(hi[ax][0], hi[ax][1], hi[ax][2], hi[ax][3]);
+                float nlo = 3e38f, nhi = -3e38f;
+                for (int k = 0; k < nk; k++) { nlo = std::min(nlo, lo[ax][k]); nhi = std::max(nhi, hi[ax][k]); }
+                org[ax] = nlo;
+                scl[ax] = std::max(nextafterf((nhi - nlo) / 255.0f, 3e38f), 1e-30f);
+                for (int k = 0; k < nk; k++) {
+                    // outward rounding with a margin, then checked against the float32 plane the device reconstructs
+                    double margin = 1e-3 + 8.0 * (double)(nextafterf(std::max(fabsf(nlo), fabsf(nhi)), 3e38f) - std::max(fabsf(nlo), fabsf(nhi))) / scl[ax];
+                    int a = (int)std::floor(((double)lo[ax][k] - org[ax]) / scl[ax] - margin);
+                    int b = (int)std::ceil(((double)hi[ax][k] - org[ax]) / scl[ax] + margin);
+                    a = std::min(std::max(a, 0), 255); b = std::min(std::max(b, 0), 255);
+                    while (a > 0 && fmaf((float)a, scl[ax], org[ax]) > lo[ax][k]) a--;
+                    while (b < 255 && fmaf((float)b, scl[ax], org[ax]) < hi[ax][k]) b++;
+                    if (fmaf((float)a, scl[ax], org[ax]) > lo[ax][k] || fmaf((float)b, scl[ax], org[ax]) < hi[ax][k])
+                        return fail(ZDR_E_INVALID, "internal error: BVH box quantisation is not conservative");
+                    qlo[ax] |= (uint32_t)a << (8 * k); qhi[ax] |= (uint32_t)b << (8 * k);
+                }
             }
-            float f[8]; memcpy(f, child, 16); memcpy(f + 4, cnt, 16);
-            o[6] = make_float4(f[0], f[1], f[2], f[3]); o[7] = make_float4(f[4], f[5], f[6], f[7]);
+            uint32_t cw[4];
+            for (int k = 0; k < 4; k++) cw[k] = (cnt[k] < 0) ? 7u : (((uint32_t)child[k] << 3) | (uint32_t)cnt[k]);
+            auto bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+            float4 *o = &nodes[4 * (size_t)it.id4];
+            o[0] = make_float4(org[0], org[1], org[2], scl[0]);
+            o[1] = make_float4(scl[1], scl[2], bits(qlo[0]), bits(qlo[1]));
+            o[2] = make_float4(bits(qlo[2]), bits(qhi[0]), bits(qhi[1]), bits(qhi[2]));
+            o[3] = make_float4(bits(cw[0]), bits(cw[1]), bits(cw[2]), bits(cw[3]));
         }
     }
     if (worst_stack + 5 > ZDR_BVH_STACK) { return fail(ZDR_E_UNSUPPORTED, "BVH needs a deeper traversal stack than ZDR_BVH_STACK"); }   // + 4 slots of slack for the unconditional stores
@@ -215,12 +239,14 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
         bool ok = true;
         if (ninner) seen_node[0] = 1;
         for (int i = 0; i < ninner && ok; i++) {
-            int ch[4], ct[4]; memcpy(ch, &nodes[8 * (size_t)i + 6], 16); memcpy(ct, &nodes[8 * (size_t)i + 7], 16);
+            uint32_t cw[4]; memcpy(cw, &nodes[4 * (size_t)i + 3], 16);
+            int ch[4], ct[4];
+            for (int k = 0; k < 4; k++) { ch[k] = (int)(cw[k] >> 3); ct[k] = (int)(cw[k] & 7u); if (ct[k] == 7) ct[k] = -1; }
             for (int k = 0; k < 4 && ok; k++) {
                 if (ct[k] < 0) continue;
                 if (ct[k] == 0) { ok = ch[k] > i && ch[k] < ninner && !seen_node[ch[k]]; if (ok) seen_node[ch[k]] = 1; }
                 else {
-                    ok = ct[k] <= 7 && ch[k] >= 0 && (uint32_t)(ch[k] + ct[k]) <= ntris;
+                    ok = ct[k] <= 4 && ch[k] >= 0 && (uint32_t)(ch[k] + ct[k]) <= ntris;
                     for (int q = 0; q < ct[k] && ok; q++) { ok = !seen_tri[ch[k] + q]; seen_tri[ch[k] + q] = 1; }
                 }
             }
@@ -390,7 +416,7 @@ extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int a
     *nnodes = nn;
     if (stack_entries) *stack_entries = se;
     if (nn > nodes_cap) return fail(ZDR_E_NOMEM, "nodes_out too small");
-    if (nn) memcpy(nodes_out, nodes.data(), (size_t)nn * 8 * sizeof(float4));
+    if (nn) memcpy(nodes_out, nodes.data(), (size_t)nn * 4 * sizeof(float4));
     for (uint32_t slot = 0; slot < ntris; slot++) {
         order_out[slot] = order[slot];
         float4 q[3]; plane_record(&pos[3 * (size_t)order[slot]], q);

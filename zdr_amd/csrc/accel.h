@@ -107,6 +107,7 @@ struct BruteAccel {
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES;       // issue-bound: more waves per SIMD buy nothing
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD;
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES;    // scratch records thrash L2 on cbox (1 instead of 2: 16.7 -> 19.0 ms)
+    static constexpr bool kFuseRays = false;                 // one walk over the pairs for both rays of a vertex measured no gain
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
         const_v4f_ptr q = as_constant(S.pairs);
@@ -176,27 +177,42 @@ struct BvhAccel {
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES_BVH;    // <= 128 VGPRs give 15 waves per CU instead of 11 (109 -> 94 ms on 1 M triangles)
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
+    static constexpr bool kFuseRays = true;                  // path_shade hands over both rays of a vertex at once (walk<true, true>)
     // 4-wide BVH, one 64-byte quantised node per visit (4 dwordx4 loads), nearest hit child first.
     // stack: this wave's LDS region, min(S.stack_entries, ZDR_BVH_LDS_STACK) x 64 ints; entry e of lane l at stack[e * 64 + l].
     // A work item is (id, cnt): cnt == 0 -> node id, 1..4 -> leaf slots [id, id + cnt); 7 marks an unused child and is never pushed.
-    template <bool ANY>
-    ZD static Hit traverse(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
-        Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
+    //
+    // One loop walks up to two rays per lane back to back: first (HAS_A) an any-hit ray — the shadow segment of a
+    // path vertex — then (HAS_B, lanes with needB) a closest-hit ray — the continuation ray.  A lane starts its second
+    // ray the moment its first one ends, so the wave's trip count is the longest SUM of the two walks over its
+    // lanes, not the sum of the two longest walks.
+    template <bool HAS_A, bool HAS_B>
+    ZD static void walk(const DScene &S, int *stack, f3 oA, f3 dA, float tminA, float tmaxA,
+                        bool needB, f3 oB, f3 dB, float tminB, float tmaxB, bool &occ, Hit &hit) {
+        occ = false;
+        hit.slot = -1; hit.u = 0.0f; hit.v = 0.0f; hit.t = tmaxB;
+        if (!HAS_A && !needB) return;
         const int lane = threadIdx.x & 63;
+        bool first = HAS_A;                                  // this lane is still on its any-hit ray
+        f3 o = HAS_A ? oA : oB, d = HAS_A ? dA : dB;
+        float tmin = HAS_A ? tminA : tminB;
+        Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = HAS_A ? tmaxA : tmaxB;
         f3 inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         // Entries [0, LN) of the stack live in LDS, deeper ones in per-lane scratch: the builder's bound
         // (up to 44 entries on a 1 M triangle tree, 11 KiB of LDS per wave) is a worst case that real rays
         // almost never approach, and LDS is what limits the waves per CU of the BVH kernels.
         const int LN = (S.stack_entries < ZDR_BVH_LDS_STACK) ? S.stack_entries : ZDR_BVH_LDS_STACK;
         int deep[ZDR_BVH_STACK - ZDR_BVH_LDS_STACK + 4];
+        const int root_cnt = (S.nnodes == 0) ? S.ntris : 0;
         int sp = 0;
-        int id = 0, cnt = (S.nnodes == 0) ? S.ntris : 0;
+        int id = 0, cnt = root_cnt;
         // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it
         // impossible for a wave to spin forever whatever the node data or the ray (NaNs) look like.
-        int budget = 2 * (S.nnodes + S.ntris) + 8;
+        const int budget0 = 2 * (S.nnodes + S.ntris) + 8;
+        int budget = budget0;
         for (;;) {
-            if (--budget < 0) break;
-            if (cnt == 0) {
+            bool ray_done = (--budget < 0);
+            if (!ray_done && cnt == 0) {
                 const float4 *n = S.nodes + 4 * (size_t)id;
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
                 // slab distances on the node's quantisation grid: t = (origin + scale q - o) / d = q A + B
@@ -211,9 +227,9 @@ struct BvhAccel {
                 float e2 = ((c2 & 7u) != 7u) ? qbox_entry<2>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
                 float e3 = ((c3 & 7u) != 7u) ? qbox_entry<3>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
                 int p0 = (int)c0, p1 = (int)c1, p2 = (int)c2, p3 = (int)c3;
-                // nearest child: visit now; the other hit children go on the stack.  The four stack
-                // writes are unconditional (LDS stores are cheap, branches are not): a slot is kept only
-                // if sp advances past it.  The builder guarantees sp + 4 <= ZDR_BVH_STACK here.
+                // nearest child: visit now; the other hit children go on the stack.  On the fast path the four
+                // stack writes are unconditional (LDS stores are cheap, branches are not): a slot is kept only
+                // if sp advances past it.
                 float em = fminf(fminf(e0, e1), fminf(e2, e3));
                 if (em < 2.0e38f) {
                     bool t0 = (e0 == em), t1 = !t0 & (e1 == em), t2 = !(t0 | t1) & (e2 == em), t3 = !(t0 | t1 | t2);
@@ -239,26 +255,45 @@ struct BvhAccel {
                     id = next >> 3; cnt = next & 7;
                     continue;
                 }
-            } else {
+            } else if (!ray_done) {
                 for (int s = id; s < id + cnt; s++) {
                     float t;
                     bool ok = tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, h.t, t);
                     if (ok) { h.t = t; h.slot = s; }
                 }
-                if (ANY && h.slot >= 0) return h;
+                if (HAS_A && first && h.slot >= 0) ray_done = true;   // any-hit: the first hit settles it
             }
-            if (sp == 0) break;
-            sp--;
-            int e = (sp < LN) ? stack[sp * 64 + lane] : deep[sp - LN];
-            id = e >> 3; cnt = e & 7;
+            if (!ray_done && sp != 0) {
+                sp--;
+                int e = (sp < LN) ? stack[sp * 64 + lane] : deep[sp - LN];
+                id = e >> 3; cnt = e & 7;
+                continue;
+            }
+            // this lane's current ray has ended
+            if (HAS_A && first) {
+                occ = h.slot >= 0;
+                if (!HAS_B || !needB) break;
+                first = false;
+                o = oB; d = dB; tmin = tminB; inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+                h.slot = -1; h.t = tmaxB;
+                sp = 0; id = 0; cnt = root_cnt; budget = budget0;
+                continue;
+            }
+            break;
         }
-        if (!ANY) hit_barycentrics(S, h, o, d);
-        return h;
+        if (HAS_B && !first && needB) { hit = h; hit_barycentrics(S, hit, oB, dB); }
     }
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
-        return traverse<false>(S, stack, o, d, tmin, tmax);
+        bool occ; Hit h;
+        walk<false, true>(S, stack, o, d, tmin, tmax, true, o, d, tmin, tmax, occ, h);
+        return h;
     }
     ZD static bool any(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
-        return traverse<true>(S, stack, o, d, tmin, tmax).slot >= 0;
+        bool occ; Hit h;
+        walk<true, false>(S, stack, o, d, tmin, tmax, false, o, d, tmin, tmax, occ, h);
+        return occ;
+    }
+    ZD static void shadow_and_closest(const DScene &S, int *stack, f3 o1, f3 d1, float tmin1, float tmax1, bool need2, f3 o2, f3 d2, bool &occ, Hit &h) {
+        walk<true, true>(S, stack, o1, d1, tmin1, tmax1, need2, o2, d2, 0.0f, 1e30f, occ, h);
     }
 };

@@ -193,7 +193,7 @@ struct PathState {
 };
 
 // One bounce of prb.py:23-87 (`for depth in range(max_depth)`) in two halves, so that the kernels can
-// order a trip as  shade vertex -> shadow ray -> sample -> trace -> classify  and every live lane
+// order a trip as  shade vertex (its two rays traced inside) -> classify the new hit  and every live lane
 // enters a trip with a vertex to shade (zdr_kernels.hip).
 //
 // path_arrive: what the ray (ps.o, ps.d) reached (prb.py:25-46).  Returns true when the path ends here
@@ -229,12 +229,20 @@ ZD bool path_arrive(const DScene &S, PathState &ps, const Hit &h, Interaction &i
     return false;
 }
 
-// path_shade: next-event estimation, BSDF sampling and Russian roulette at the vertex `it`
-// (prb.py:47-87).  Returns true when the path stops here; otherwise (ps.o, ps.d) is the next ray.
+// path_shade: next-event estimation, BSDF sampling, Russian roulette and the tracing of both rays of the
+// vertex `it` (prb.py:47-87 and the trace_closest of the next loop trip, prb.py:25).  Returns true when the path
+// stops at this vertex; otherwise (ps.o, ps.d) is the continuation ray and — after path_continue — `h` what it hit.
+// The sampler draws always come in the reference's order (light pick, light point, lobe, direction, roulette).
+// A::kFuseRays selects WHEN the shadow ray is traced:
+//   false (brute force)  shadow ray -> NEE -> BSDF sampling, as the reference; the continuation ray is traced by
+//                        path_continue, which the backward kernel calls once the vertex record has left the registers;
+//   true  (BVH)          BSDF sampling first, then both rays in ONE traversal loop (a lane starts its continuation
+//                        ray as soon as its shadow ray has ended), then the NEE contribution — which only needs
+//                        the throughput that ARRIVED at the vertex.
 // BWD: fills pv, the record of this vertex.
 template <int SK, class A, bool BWD, bool STATS, bool ENV>
 ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                   PathState &ps, const Interaction &it, PathVertex &pv, Counters &cnt) {
+                   PathState &ps, const Interaction &it, PathVertex &pv, Hit &h, Counters &cnt) {
     float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
     f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
     COUNT(C_SHADED);
@@ -244,68 +252,91 @@ ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, con
     }
     Onb onb = make_onb(it.ns);
     f3 wo = to_local(onb, -ps.d);
-    // next-event estimation (prb.py:57-66)
+    // next-event estimation: the light sample (prb.py:57-58)
     float u_pick = sampler_next<SK>(C, ps.smp);
     LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
-    COUNT(C_SHADOW);
-    bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
-    f3 wil = to_local(onb, light.wi);
-    if (!occluded && wil.z >= 1e-4f) {
-        GgxTerms g = ggx_terms(wo, wil, roughness);
-        f3 bsdf = ggx_brdf_from(g, wil, diffuse);
-        float pb = ggx_pdf_from(g, wo, wil);
-        float mis = balanced_heuristic(light.pdf, pb);
-        float inv_dn = rcp(fmaxf(light.pdf, 1e-4f));
-        ps.L = ps.L + (((ps.beta * bsdf) * mis) * light.eval) * inv_dn;
-        if (BWD) {
-            f3 W = (light.eval * mis) * inv_dn;
-            float dlnpL;
-            pv.bW = ps.beta * W; pv.cL = wil.z * ZDR_INV_PI; pv.dfLdr = ggx_dfdr_from(g, wo, wil, roughness, dlnpL);
-            pv.fLW = bsdf * W;
-            float pbf = (light.pdf + pb > 1e-4f) ? pb * rcp(light.pdf + pb) : 0.0f;   // d w_nee/dr = -w_nee pb/(pl+pb) dln(pb)/dr
-            pv.neeM = ((ps.beta * bsdf) * W) * (pbf * dlnpL);
-        }
-    }
-    // BSDF sampling (prb.py:69-76)
-    float u_lobe = sampler_next<SK>(C, ps.smp);
-    f2 u_dir = sampler_next2<SK>(C, ps.smp);
-    f3 wi_local = ggx_sample(wo, roughness, u_lobe, u_dir);
-    GgxTerms g = ggx_terms(wo, wi_local, roughness);
-    ps.pdf_bsdf = ggx_pdf_from(g, wo, wi_local);
-    f3 wi = to_world(onb, wi_local);
-    bool stop = (dot(wi, it.ng) < 1e-4f) || (wi_local.z < 1e-4f);                 // prb.py:73-74
-    f3 beta_in = ps.beta;
-    float q = 1.0f;
-    int rr_kind = 0;
-    if (!stop) {
-        ps.o = offset_ray_origin(it.p, it.ng); ps.d = wi;
-        f3 f = ggx_brdf_from(g, wi_local, diffuse);
-        float inv_p = rcp(ps.pdf_bsdf);
-        ps.beta = ps.beta * (f * inv_p);
-        if (ps.depth >= R.rr_depth) {                                             // prb.py:79-87
-            float l = 0.212671f * ps.beta.x + 0.715160f * ps.beta.y + 0.072169f * ps.beta.z;
-            if (l == 0.0f) stop = true;
-            else {
-                q = fmaxf(l, 0.05f);
-                float r = sampler_next<SK>(C, ps.smp);
-                if (r >= q) stop = true;
-                else { ps.beta = ps.beta * rcp(q); rr_kind = (l >= 1.0f) ? 2 : ((l >= 0.05f) ? 1 : 0); }
+    const f3 wil = to_local(onb, light.wi);
+
+    auto nee = [&](bool occluded, f3 beta_in) {                                   // prb.py:60-66; beta_in: throughput arriving at the vertex
+        if (!occluded && wil.z >= 1e-4f) {
+            GgxTerms g = ggx_terms(wo, wil, roughness);
+            f3 bsdf = ggx_brdf_from(g, wil, diffuse);
+            float pb = ggx_pdf_from(g, wo, wil);
+            float mis = balanced_heuristic(light.pdf, pb);
+            float inv_dn = rcp(fmaxf(light.pdf, 1e-4f));
+            ps.L = ps.L + (((beta_in * bsdf) * mis) * light.eval) * inv_dn;
+            if (BWD) {
+                f3 W = (light.eval * mis) * inv_dn;
+                float dlnpL;
+                pv.bW = beta_in * W; pv.cL = wil.z * ZDR_INV_PI; pv.dfLdr = ggx_dfdr_from(g, wo, wil, roughness, dlnpL);
+                pv.fLW = bsdf * W;
+                float pbf = (light.pdf + pb > 1e-4f) ? pb * rcp(light.pdf + pb) : 0.0f;   // d w_nee/dr = -w_nee pb/(pl+pb) dln(pb)/dr
+                pv.neeM = ((beta_in * bsdf) * W) * (pbf * dlnpL);
             }
         }
-        if (BWD && !stop) {
-            float inv_pq = inv_p * rcp(q);
-            pv.bpq = beta_in * inv_pq; pv.c = wi_local.z * ZDR_INV_PI; pv.dfdr = ggx_dfdr_from(g, wo, wi_local, roughness, pv.dlnp);
-            pv.T = f * inv_pq;
-            // prb.py:83 has no upper clamp on q: for lum(beta') >= 1 the path survives with certainty and is
-            // STILL divided by q = lum(beta'), i.e. beta leaves this vertex with unit luminance.  The forward's
-            // expectation then depends on q(material); the sweep differentiates through it (sweep_vertex).
-            pv.rr = rr_kind;
-            if (rr_kind == 2) pv.bnorm = ps.beta;
+    };
+    auto sample_bsdf = [&]() -> bool {                                            // prb.py:69-87; true = the path stops here
+        float u_lobe = sampler_next<SK>(C, ps.smp);
+        f2 u_dir = sampler_next2<SK>(C, ps.smp);
+        f3 wi_local = ggx_sample(wo, roughness, u_lobe, u_dir);
+        GgxTerms g = ggx_terms(wo, wi_local, roughness);
+        ps.pdf_bsdf = ggx_pdf_from(g, wo, wi_local);
+        f3 wi = to_world(onb, wi_local);
+        bool stop = (dot(wi, it.ng) < 1e-4f) || (wi_local.z < 1e-4f);             // prb.py:73-74
+        const f3 beta_in = ps.beta;
+        float q = 1.0f;
+        int rr_kind = 0;
+        if (!stop) {
+            ps.o = offset_ray_origin(it.p, it.ng); ps.d = wi;
+            f3 f = ggx_brdf_from(g, wi_local, diffuse);
+            float inv_p = rcp(ps.pdf_bsdf);
+            ps.beta = ps.beta * (f * inv_p);
+            if (ps.depth >= R.rr_depth) {                                         // prb.py:79-87
+                float l = 0.212671f * ps.beta.x + 0.715160f * ps.beta.y + 0.072169f * ps.beta.z;
+                if (l == 0.0f) stop = true;
+                else {
+                    q = fmaxf(l, 0.05f);
+                    float r = sampler_next<SK>(C, ps.smp);
+                    if (r >= q) stop = true;
+                    else { ps.beta = ps.beta * rcp(q); rr_kind = (l >= 1.0f) ? 2 : ((l >= 0.05f) ? 1 : 0); }
+                }
+            }
+            if (BWD && !stop) {
+                float inv_pq = inv_p * rcp(q);
+                pv.bpq = beta_in * inv_pq; pv.c = wi_local.z * ZDR_INV_PI; pv.dfdr = ggx_dfdr_from(g, wo, wi_local, roughness, pv.dlnp);
+                pv.T = f * inv_pq;
+                // prb.py:83 has no upper clamp on q: for lum(beta') >= 1 the path survives with certainty and is
+                // STILL divided by q = lum(beta'), i.e. beta leaves this vertex with unit luminance.  The forward's
+                // expectation then depends on q(material); the sweep differentiates through it (sweep_vertex).
+                pv.rr = rr_kind;
+                if (rr_kind == 2) pv.bnorm = ps.beta;
+            }
         }
+        ps.depth++;
+        if (ps.depth >= R.max_depth) stop = true;
+        return stop;
+    };
+
+    COUNT(C_SHADOW);
+    bool stop;
+    if constexpr (A::kFuseRays) {
+        const f3 beta_arrived = ps.beta;
+        stop = sample_bsdf();
+        if (!stop) COUNT(C_CLOSEST);
+        bool occluded;
+        A::shadow_and_closest(S, lds, it.p, light.wi, 1e-4f, light.dist, !stop, ps.o, ps.d, occluded, h);
+        nee(occluded, beta_arrived);
+    } else {
+        nee(A::any(S, lds, it.p, light.wi, 1e-4f, light.dist), ps.beta);
+        stop = sample_bsdf();              // the caller traces the continuation ray (path_continue), after it has put pv away
     }
-    ps.depth++;
-    if (ps.depth >= R.max_depth) stop = true;
     return stop;
+}
+
+// The continuation ray of a vertex whose path goes on: already traced by path_shade when A::kFuseRays.
+template <class A, bool STATS>
+ZD void path_continue(const DScene &S, int *lds, const PathState &ps, Hit &h, Counters &cnt) {
+    if constexpr (!A::kFuseRays) { COUNT(C_CLOSEST); h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f); }
 }
 
 // ---- primary queue -----------------------------------------------------------------------------

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WAVE) void k_tile_masks(DScene S, RenderCfg R, unsi
 //   refill  lane = pixel: ZDR_RING_BATCH camera samples per pixel of the current item are generated, traced
 //           and classified by the whole wave and the vertices to shade are parked in the wave's FIFO;
 //   flat loop  a lane is just a worker: it takes the next parked vertex (of ANY pixel) and each trip
-//           shades one vertex:  shade -> shadow ray -> BSDF sample -> trace -> classify.
+//           shades one vertex:  shade (light sample, BSDF sample, the vertex's two rays) -> classify the new hit.
 // Items overlap: when the current item has no camera sample left the wave starts the next one while the last
 // paths of the old one are still running, so lanes never wait for a tile's longest path.  Per-pixel state
 // (radiance sums, CMJ seeds) therefore lives in LDS in two banks, item n in bank n & 1; a path carries its
@@ -227,12 +227,9 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesFwd) void k_path(DScene S, Render
             progress = true;
             bool done = false;
             if (alive) {
-                done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, cnt);
-                if (!done) {
-                    COUNT(C_CLOSEST);
-                    Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
-                    done = path_arrive<false, STATS, ENV>(S, ps, h, it, term_Li, cnt);
-                }
+                Hit h;
+                done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
+                if (!done) { path_continue<A, STATS>(S, lds, ps, h, cnt); done = path_arrive<false, STATS, ENV>(S, ps, h, it, term_Li, cnt); }
                 if (done) {
                     alive = false;
                     if (!any_nan(ps.L)) {                   // integrator.py:27-28
@@ -349,7 +346,8 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
             if (alive) {
                 PathVertex pv; float term_plfrac = 0.0f;
-                done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, cnt);
+                Hit h;
+                done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
                 {
                     PackedVertex p = pack_vertex(pv, le_grad);
                     if (nrec < lds_vertices) {
@@ -359,10 +357,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
                     } else deep[nrec] = p;
                     nrec++;
                 }
-                if (!done) {
-                    Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
-                    done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac);
-                }
+                if (!done) { path_continue<A, false>(S, lds, ps, h, cnt); done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac); }
                 if (done) {
                     alive = false;
                     if (!any_nan(ps.L) && nrec > 0) {       // prb.py:100: NaN paths contribute nothing

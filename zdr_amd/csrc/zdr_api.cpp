@@ -41,7 +41,11 @@ static void normal_matrix(const float *m, float *n) {      // inverse(transpose(
 }
 
 // ------------------------------------------------------------------------------ BVH builder
-// Binned SAH (16 bins, 3 axes), leaves of <= 4 triangles, depth bounded by the traversal stack.
+// Binned SAH (16 bins, 3 axes), leaves of <= ZDR_BVH_LEAF triangles, depth bounded by the traversal stack.
+#ifndef ZDR_BVH_LEAF
+#define ZDR_BVH_LEAF 2   // 1 M triangles, path fwd / bwd ms at 1024^2 spp 32: leaf 1: 46 / 61, 2: 42 / 56, 3: 43 / 58, 4: 48 / 64, 6: 54 / 72 (a triangle costs three per-lane loads, a node four)
+#endif
+static_assert(ZDR_BVH_LEAF >= 1 && ZDR_BVH_LEAF <= 6, "the child word holds the leaf size in 3 bits, 7 = unused");
 struct BNode { float lo[3], hi[3]; int left, right, first, count; };
 struct Prim { float lo[3], hi[3], c[3]; int tri; };
 
@@ -49,7 +53,7 @@ struct BvhBuilder {
     std::vector<Prim> prims;
     std::vector<BNode> nodes;
     int max_depth = 0;
-    static constexpr int kLeaf = 4, kBins = 16, kDepthLimit = ZDR_BVH_STACK - 2;
+    static constexpr int kLeaf = ZDR_BVH_LEAF, kBins = 16, kDepthLimit = ZDR_BVH_STACK - 2;
 
     static void grow(float *lo, float *hi, const float *plo, const float *phi) {
         for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], plo[k]); hi[k] = std::max(hi[k], phi[k]); }
@@ -246,7 +250,7 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
                 if (ct[k] < 0) continue;
                 if (ct[k] == 0) { ok = ch[k] > i && ch[k] < ninner && !seen_node[ch[k]]; if (ok) seen_node[ch[k]] = 1; }
                 else {
-                    ok = ct[k] <= 4 && ch[k] >= 0 && (uint32_t)(ch[k] + ct[k]) <= ntris;
+                    ok = ct[k] <= ZDR_BVH_LEAF && ch[k] >= 0 && (uint32_t)(ch[k] + ct[k]) <= ntris;
                     for (int q = 0; q < ct[k] && ok; q++) { ok = !seen_tri[ch[k] + q]; seen_tri[ch[k] + q] = 1; }
                 }
             }

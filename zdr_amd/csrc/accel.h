@@ -29,9 +29,6 @@
 #define ZDR_LDS_VERTICES_BVH 1
 #endif
 
-#ifndef ZDR_TRI_UNROLL
-#define ZDR_TRI_UNROLL 1
-#endif
 
 
 // The triangle array is read-only for the whole launch.  Reading it through the CONSTANT address

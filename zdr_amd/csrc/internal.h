@@ -43,7 +43,7 @@ struct KernelIO {
     unsigned long long *counters;     // stats variant: 8 counters
     const unsigned long long *tile_masks;   // brute-force accel: per 8x8 tile, the triangle pairs its camera rays can hit (k_tile_masks); null = all
     unsigned int *work_counters;      // path integrator: 8 item counters, one per XCD, zeroed before the launch (fetch_item)
-    float4 *ring;                     // path integrator: per-block rings of parked camera-ray vertices (integrators.h)
+    float4 *ring;                     // path integrator: one FIFO of parked camera-ray vertices per persistent workgroup (integrators.h)
 };
 
 int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,

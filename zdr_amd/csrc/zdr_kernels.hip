@@ -1,10 +1,10 @@
 // zdr_kernels.hip — gfx950 kernels of the zdr hot path and their launchers.
 //
-// Mapping: a 64-lane wavefront = one 8x8 pixel tile x one chunk of the sample
-// range; lane = pixel.  Workgroups are single waves, so no workgroup barrier exists anywhere and
-// the hardware can retire/dispatch waves individually (paths have very uneven lengths).  The
-// block index is remapped so that each XCD (blocks b, b+8, ... share one) receives a contiguous
-// run of tiles: primary-hit texel footprints of neighbouring tiles then share that XCD's L2.
+// Work item = one 8x8 pixel tile x one chunk of the sample range; workgroups are single 64-lane waves, so
+// no workgroup barrier exists anywhere.  The direct / collocated / uvgrad kernels run one workgroup per item
+// (lane = pixel), the block index remapped so that each XCD (blocks b, b+8, ... share one) receives a contiguous
+// run of tiles: primary-hit texel footprints of neighbouring tiles then share that XCD's L2.  The path kernels are
+// persistent waves that draw items from per-XCD counters and treat lanes as workers (see k_path).
 #include <algorithm>
 #include <cstdlib>
 #include <map>

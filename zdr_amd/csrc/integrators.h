@@ -396,6 +396,8 @@ ZD void primary_refill(const DScene &S, const RenderCfg &R, const SamplerCfg &C,
         }
         q.tail += (uint32_t)__popcll(m);
     }
+    // entries are read back by OTHER lanes of this wave: order the stores before the later loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
 // An idle lane takes the oldest parked vertex that no lower idle lane takes: the path state as it is right
@@ -408,6 +410,7 @@ ZD int primary_pop(const DScene &S, const SamplerCfg &C, bool idle, const uint32
     const uint32_t avail = q.tail - q.head, rank = lane_rank(m), want = (uint32_t)__popcll(m);
     const bool take = idle && rank < avail;
     int pix = -1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (take) {
         const float4 *e = q.base + (size_t)((q.head + rank) % ZDR_QUEUE_ENTRIES) * 2;
         float4 a = e[0], b = e[1];

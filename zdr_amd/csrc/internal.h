@@ -30,7 +30,7 @@ struct RenderCfg {
     float inv_spp;                             // 1 / spp as computed by IEEE division
     float alpha;                               // (sample_end - sample_begin) / spp
     float cam_o[3], cam_fwd[3], cam_right[3], cam_upp[3], cam_tan;   // camera.py:12-15
-    int32_t debug_no_scatter;         // timing-only ablation (env ZDR_DEBUG_NO_SCATTER): gradients are computed, not added
+    int32_t debug_no_scatter;         // timing-only ablations (env ZDR_DEBUG_NO_SCATTER): 1 gradients computed, not added; 2 atomics confined to 64 KiB; 3 no sweep
 };
 
 struct KernelIO {

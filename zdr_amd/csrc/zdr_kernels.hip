@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
                 if (done) {
                     alive = false;
                     if (!any_nan(ps.L) && nrec > 0) {       // prb.py:100: NaN paths contribute nothing
-                        sw_k = nrec - 1;
+                        sw_k = (R.debug_no_scatter == 3) ? -1 : nrec - 1;   // ablation 3: no sweep at all
                         sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f;
                         sw.tw = term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
                     }

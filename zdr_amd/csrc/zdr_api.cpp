@@ -42,6 +42,9 @@ static void normal_matrix(const float *m, float *n) {      // inverse(transpose(
 
 // ------------------------------------------------------------------------------ BVH builder
 // Binned SAH (16 bins, 3 axes), leaves of <= ZDR_BVH_LEAF triangles, depth bounded by the traversal stack.
+#ifndef ZDR_BVH_BINS
+#define ZDR_BVH_BINS 16
+#endif
 #ifndef ZDR_BVH_LEAF
 #define ZDR_BVH_LEAF 2   // 1 M triangles, path fwd / bwd ms at 1024^2 spp 32: leaf 1: 46 / 61, 2: 42 / 56, 3: 43 / 58, 4: 48 / 64, 6: 54 / 72 (a triangle costs three per-lane loads, a node four)
 #endif
@@ -53,7 +56,7 @@ struct BvhBuilder {
     std::vector<Prim> prims;
     std::vector<BNode> nodes;
     int max_depth = 0;
-    static constexpr int kLeaf = ZDR_BVH_LEAF, kBins = 16, kDepthLimit = ZDR_BVH_STACK - 2;
+    static constexpr int kLeaf = ZDR_BVH_LEAF, kBins = ZDR_BVH_BINS, kDepthLimit = ZDR_BVH_STACK - 2;
 
     static void grow(float *lo, float *hi, const float *plo, const float *phi) {
         for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], plo[k]); hi[k] = std::max(hi[k], phi[k]); }

@@ -202,6 +202,27 @@ def test_work_item_granularity_only_reassociates(accel, mat_b, monkeypatch):
         assert st == out[0][2]                                   # the very same paths: identical counters
 
 
+@pytest.mark.parametrize("integrator", ["direct", "path"])
+def test_shards_at_odd_offsets(integrator, mat_a):
+    """Shard rectangles need not sit on the 8x8 tile grid of the full image: tiles are laid out from the
+    rectangle's own corner, so the same pixel lands in different tiles (and lanes) — only the order of the
+    float additions may change."""
+    scene = make_scene(integrator)
+    m = torch.from_numpy(mat_a).cuda()
+    W, H, spp = 61, 45, 32
+    full = scene.render_forward(m, (W, H), spp, 8)
+    parts = torch.zeros_like(full)
+    for rect in [(0, 0, 13, 45), (13, 0, 61, 7), (13, 7, 38, 45), (38, 7, 61, 45)]:
+        scene.render_forward(m, (W, H), spp, 8, rect=rect, out=parts)
+    torch.testing.assert_close(parts, full, rtol=2e-5, atol=1e-6)
+    cot = torch.from_numpy(np.random.default_rng(2).uniform(0.5, 1.5, (H, W, 4)).astype(np.float32)).cuda()
+    g_full = torch.zeros_like(m); g_parts = torch.zeros_like(m)
+    scene.render_backward(cot, g_full, m, (W, H), spp, 8)
+    for rect in [(0, 0, 61, 11), (0, 11, 29, 45), (29, 11, 61, 45)]:
+        scene.render_backward(cot, g_parts, m, (W, H), spp, 8, rect=rect)
+    torch.testing.assert_close(g_parts, g_full, rtol=1e-4, atol=1e-6 * float(g_full.abs().max()))
+
+
 def test_stats_match_oracle_counters(cbox_oracle, mat_a):
     scene = make_scene("path")
     m = torch.from_numpy(mat_a).cuda()

@@ -342,6 +342,8 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             // sweep state: set when a path ends and used up before the trip is over — local to the trip, so that it
             // holds no registers while the vertex is shaded
             f3 term_Li = mk3(0.0f);
+            PackedVertex plast;                             // the vertex shaded this trip, as recorded
+            plast.a = plast.b = plast.c = plast.d = plast.e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             int sw_k = -1;                                  // next vertex the sweep consumes
             SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
             if (alive) {
@@ -349,12 +351,13 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
                 Hit h;
                 done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
                 {
-                    PackedVertex p = pack_vertex(pv, le_grad);
+                    plast = pack_vertex(pv, le_grad);
                     if (nrec < lds_vertices) {
                         float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
-                        r[0] = p.a; r[WAVE] = p.b; r[2 * WAVE] = p.c; r[3 * WAVE] = p.d;
-                        lds_dlnp[nrec * WAVE + lane] = p.e.w;
-                    } else deep[nrec] = p;
+                        r[0] = plast.a; r[WAVE] = plast.b; r[2 * WAVE] = plast.c; r[3 * WAVE] = plast.d;
+                        lds_dlnp[nrec * WAVE + lane] = plast.e.w;
+                        plast.e = make_float4(0.0f, 0.0f, 0.0f, plast.e.w);     // as it will read back: LDS records carry no RR fields
+                    } else deep[nrec] = plast;
                     nrec++;
                 }
                 if (!done) { path_continue<A, false>(S, lds, ps, h, cnt); done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac); }
@@ -369,21 +372,26 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             }
             ib.inflight[0] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 0));
             ib.inflight[1] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 1));
-            while (__ballot(sw_k >= 0) != 0ull) {           // wave-uniform: sweep every finished path to its first vertex
+            // wave-uniform: sweep every finished path to its first vertex.  The sweep starts from the vertex packed this
+            // trip (still in registers) and the record of the NEXT step is fetched before the current one is processed, so
+            // that a scratch read (records beyond the LDS ones) is under way while the gradient is computed and queued.
+            PackedVertex cur = plast;
+            while (__ballot(sw_k >= 0) != 0ull) {
                 const bool swp = sw_k >= 0;
+                PackedVertex nxt = cur;
+                if (swp && sw_k >= 1) {
+                    const int k = sw_k - 1;
+                    if (k < lds_vertices) {
+                        const float4 *r = lds_rec + (k * 4) * WAVE + lane;
+                        nxt.a = r[0]; nxt.b = r[WAVE]; nxt.c = r[2 * WAVE]; nxt.d = r[3 * WAVE];
+                        nxt.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[k * WAVE + lane]);
+                    } else nxt = deep[k];
+                }
                 float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 f2 guv; guv.x = 0.0f; guv.y = 0.0f;
-                if (swp) {
-                    PackedVertex p;
-                    if (sw_k < lds_vertices) {
-                        const float4 *r = lds_rec + (sw_k * 4) * WAVE + lane;
-                        p.a = r[0]; p.b = r[WAVE]; p.c = r[2 * WAVE]; p.d = r[3 * WAVE];
-                        p.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[sw_k * WAVE + lane]);
-                    } else p = deep[sw_k];
-                    g = sweep_vertex(p, sw, guv);
-                    sw_k--;
-                }
+                if (swp) { g = sweep_vertex(cur, sw, guv); sw_k--; }
                 scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
+                cur = nxt;
             }
         }
 #pragma unroll

@@ -102,7 +102,7 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     COUNT(C_HITS);
     Interaction it = surface_interact(S, h);
     if (dot(-d, it.ng) < 1e-4f || dot(-d, it.ns) < 1e-4f) return mk3(0.0f);
-    if (it.inst > 0) return ld3(S.emission + 3 * it.inst);                        // direct.py:30-32
+    if (it.inst > 0) return xyz(S.emission4[it.inst]);                            // direct.py:30-32
     float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
     f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
     COUNT(C_SHADED);
@@ -142,7 +142,7 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
             COUNT(C_HITS);
             Interaction it2 = surface_interact(S, h2);
             if (!(dot(-wi, it2.ng) < 1e-4f || dot(-wi, it2.ns) < 1e-4f)) {
-                em = ld3(S.emission + 3 * it2.inst);
+                em = xyz(S.emission4[it2.inst]);
                 pdf_light = sample_light_pdf<ENV>(S, it.p, it2.inst, h2.slot, it2.p);   // origin = it.p (direct.py:66)
                 lit = true;
             }
@@ -215,7 +215,7 @@ ZD bool path_arrive(const DScene &S, PathState &ps, const Hit &h, Interaction &i
     COUNT(C_HITS);
     it = surface_interact(S, h);
     if (dot(-ps.d, it.ng) < 1e-4f || dot(-ps.d, it.ns) < 1e-4f) return true;      // prb.py:35-36
-    f3 em = ld3(S.emission + 3 * it.inst);
+    f3 em = xyz(S.emission4[it.inst]);
     if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {                              // prb.py:39-44
         float pdf_light = sample_light_pdf<ENV>(S, ps.o, it.inst, h.slot, it.p);
         float mis = balanced_heuristic(ps.pdf_bsdf, pdf_light);

@@ -29,6 +29,10 @@ struct DScene {
     const int32_t *light_insts;     // ninst       (heap slot 23334)
     const int32_t *inst_tri_begin;  // ninst + 1   (heap slot 23335 holds the counts)
     const int32_t *slot_of_tri;     // input triangle index -> slot
+    // flat light table: light l covers entries [light_range[2l], + light_range[2l+1]); entry = five float4
+    //   {p0} {p1} {p2} {ng, area} {emission, 0}   (the floats of the shade records and of `emission`)
+    const float4 *light_tris; const int32_t *light_range; const float4 *emission4;   // emission4: ninst x {e.rgb, 0}
+    int32_t light0_T;               // triangle count of light 0 (the whole table when light_count == 1)
     int32_t ntris, ninst, light_count, nnodes;
     // environment light (envmap.py; heap slots 23330-23332): lat-long RGBA texture + importance tables
     const float4 *env_tex; const float *alias_prob; const int32_t *alias_idx; const float *env_pdf;
@@ -247,19 +251,19 @@ ZD LightSample sample_light(const DScene &S, f3 origin, float u_pick, NEXT1 next
     if (ENV) idx -= S.env_count;
     float u_prim = next1();
     f2 u_pt = next2();
-    int inst = S.light_insts[idx];
-    int b = S.inst_tri_begin[inst];
-    int T = S.inst_tri_begin[inst + 1] - b;
+    // light.py:33-48 walks light -> instance -> triangle range -> triangle -> emission; the flat table makes that one
+    // lookup (none for a single light) + the entry
+    int base = 0, T = S.light0_T;
+    if (S.light_count > 1) { base = S.light_range[2 * idx]; T = S.light_range[2 * idx + 1]; }
     int prim = clampi((int)(u_prim * (float)T), 0, T - 1);
-    const float4 *r = S.shade + 8 * (size_t)S.slot_of_tri[b + prim];
-    float4 r0 = r[0], r1 = r[1], r2 = r[2], r6 = r[6];
+    const float4 *r = S.light_tris + 5 * (size_t)(base + prim);
+    float4 r0 = r[0], r1 = r[1], r2 = r[2], r6 = r[3], r4 = r[4];
     f3 abc = sample_uniform_triangle(u_pt);
     f3 p = xyz(r0) * abc.x + xyz(r1) * abc.y + xyz(r2) * abc.z;
     float cos_light, sqr_dist;
     L.pdf = light_pdf(origin, p, xyz(r6), r6.w, n * T, L.wi, cos_light, sqr_dist);
     L.dist = 0.9999f * fsqrt(sqr_dist);
-    f3 e = ld3(S.emission + 3 * inst);
-    L.eval = (cos_light > 1e-4f) ? e : mk3(0.0f);
+    L.eval = (cos_light > 1e-4f) ? xyz(r4) : mk3(0.0f);
     return L;
 }
 

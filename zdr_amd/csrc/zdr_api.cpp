@@ -277,6 +277,11 @@ struct zdr_scene {
     std::vector<float> emission;
     float4 *d_isect = nullptr, *d_pairs = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
     float *d_emission = nullptr;
+    // flat light table (scene.h): one 80-byte entry per triangle of every emitting instance + {first entry, count} per light
+    std::vector<float4> tri_geo;            // host copy, 4 float4 per INPUT triangle: p0, p1, p2, {ng, area} (lights may change)
+    float4 *d_light_tris = nullptr; size_t light_tris_cap = 0;
+    int32_t *d_light_range = nullptr;       // 2 ints per instance slot
+    float4 *d_emission4 = nullptr;          // ninst x {e.rgb, 0}
     int32_t *d_light_insts = nullptr, *d_inst_tri_begin = nullptr, *d_slot_of_tri = nullptr;
     uint32_t *d_pmj = nullptr; uint16_t *d_bn = nullptr; SamplerTables tab{};
     float4 *d_env_tex = nullptr; float *d_alias_prob = nullptr, *d_env_pdf = nullptr; int32_t *d_alias_idx = nullptr;
@@ -302,6 +307,40 @@ static void light_list(const std::vector<float> &em, uint32_t ninst, std::vector
     out.assign(ninst, 0); count = 0;     // render.py:89-90,118-121,146-148
     for (uint32_t i = 0; i < ninst; i++)
         if (em[3 * i] > 0.0f || em[3 * i + 1] > 0.0f || em[3 * i + 2] > 0.0f) out[count++] = (int32_t)i;
+}
+
+// Light table for sample_light (scene.h): the reference walks light -> instance -> triangle range -> triangle ->
+// emission through four dependent lookups (light.py:33-48); on the GPU that is four memory round trips and eleven
+// per-lane loads per path vertex.  Flattened here to {first entry, T} per light and one 80-byte entry per light
+// triangle {p0} {p1} {p2} {ng, area} {emission, 0}, the same floats the shade records hold.
+static int upload_light_table(zdr_scene *s, const std::vector<int32_t> &lights, int count, hipStream_t st) {
+    std::vector<float4> tab; std::vector<int32_t> range(2 * (size_t)s->ninst, 0);
+    for (int l = 0; l < count; l++) {
+        const int inst = lights[l], b = s->inst_tri_begin[inst], T = s->inst_tri_begin[inst + 1] - b;
+        range[2 * l] = (int32_t)(tab.size() / 5); range[2 * l + 1] = T;
+        for (int t = b; t < b + T; t++) {
+            for (int k = 0; k < 4; k++) tab.push_back(s->tri_geo[4 * (size_t)t + k]);
+            tab.push_back(make_float4(s->emission[3 * (size_t)inst], s->emission[3 * (size_t)inst + 1], s->emission[3 * (size_t)inst + 2], 0.0f));
+        }
+    }
+    if (tab.empty()) tab.push_back(make_float4(0, 0, 0, 0));
+    if (tab.size() > s->light_tris_cap) {
+        HIPCHK(hipStreamSynchronize(st));
+        (void)hipFree(s->d_light_tris); s->d_light_tris = nullptr; s->light_tris_cap = 0;
+        HIPCHK(hipMalloc((void **)&s->d_light_tris, tab.size() * sizeof(float4)));
+        s->light_tris_cap = tab.size();
+    }
+    if (!s->d_light_range) HIPCHK(hipMalloc((void **)&s->d_light_range, range.size() * sizeof(int32_t)));
+    if (!s->d_emission4) HIPCHK(hipMalloc((void **)&s->d_emission4, (size_t)s->ninst * sizeof(float4)));
+    std::vector<float4> e4(s->ninst);
+    for (uint32_t i = 0; i < s->ninst; i++) e4[i] = make_float4(s->emission[3 * (size_t)i], s->emission[3 * (size_t)i + 1], s->emission[3 * (size_t)i + 2], 0.0f);
+    HIPCHK(hipMemcpyAsync(s->d_light_tris, tab.data(), tab.size() * sizeof(float4), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->d_light_range, range.data(), range.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->d_emission4, e4.data(), e4.size() * sizeof(float4), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));       // the host vectors go out of scope
+    s->ds.light_tris = s->d_light_tris; s->ds.light_range = s->d_light_range; s->ds.emission4 = s->d_emission4;
+    s->ds.light0_T = count > 0 ? range[1] : 0;
+    return ZDR_OK;
 }
 
 extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int32_t *tris, uint32_t ntris,
@@ -380,6 +419,14 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     }
     std::vector<int32_t> lights; int light_count = 0;
     light_list(s->emission, ninst, lights, light_count);
+    s->tri_geo.resize(4 * (size_t)ntris);
+    for (uint32_t t = 0; t < ntris; t++) {
+        const TriRec &r = rec[t];
+        s->tri_geo[4 * (size_t)t] = make_float4(r.p[0].x, r.p[0].y, r.p[0].z, 0.0f);
+        s->tri_geo[4 * (size_t)t + 1] = make_float4(r.p[1].x, r.p[1].y, r.p[1].z, 0.0f);
+        s->tri_geo[4 * (size_t)t + 2] = make_float4(r.p[2].x, r.p[2].y, r.p[2].z, 0.0f);
+        s->tri_geo[4 * (size_t)t + 3] = make_float4(r.ng.x, r.ng.y, r.ng.z, r.area);
+    }
 
     hipError_t e = hipSuccess;
     auto up = [&](auto **dst, const void *src, size_t bytes) { if (e == hipSuccess) e = upload(dst, src, bytes, &s->device_bytes); };
@@ -406,6 +453,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     s->ds.isect = s->d_isect; s->ds.pairs = s->d_pairs; s->ds.shade = s->d_shade; s->ds.nodes = s->d_nodes; s->ds.emission = s->d_emission;
     s->ds.light_insts = s->d_light_insts; s->ds.inst_tri_begin = s->d_inst_tri_begin; s->ds.slot_of_tri = s->d_slot_of_tri;
     s->ds.ntris = (int32_t)ntris; s->ds.ninst = (int32_t)ninst; s->ds.light_count = light_count; s->ds.nnodes = (int32_t)s->bvh_nodes; s->ds.stack_entries = (int32_t)s->stack_entries;
+    { int rc = upload_light_table(s, lights, light_count, nullptr); if (rc) { zdr_scene_destroy(s); return rc; } }
     *out = s;
     return ZDR_OK;
 }
@@ -435,7 +483,7 @@ extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int a
 extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
-    (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts);
+    (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts); (void)hipFree(s->d_light_tris); (void)hipFree(s->d_light_range); (void)hipFree(s->d_emission4);
     (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
     delete s;
     return ZDR_OK;
@@ -461,7 +509,7 @@ extern "C" int zdr_scene_set_emissions(zdr_scene *s, const float *inst_emission,
     HIPCHK(hipMemcpyAsync(s->d_light_insts, lights.data(), lights.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     s->ds.light_count = count;
-    return ZDR_OK;
+    return upload_light_table(s, lights, count, st);
 }
 
 extern "C" int zdr_scene_set_envmap(zdr_scene *s, const float *tex, uint32_t tex_h, uint32_t tex_w, const float *alias_prob,

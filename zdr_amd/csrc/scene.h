@@ -14,8 +14,8 @@
 //   shade[8*slot + ...]     = one 128-byte line:                       (surface_interact, lights)
 //     r0 {p0.xyz, uv0.x} r1 {p1.xyz, uv0.y} r2 {p2.xyz, uv1.x}
 //     r3 {n0.xyz, uv1.y} r4 {n1.xyz, uv2.x} r5 {n2.xyz, uv2.y}   n_i = inverse-transpose(M) * vn_i
-//     r6 {ng.xyz, area}                                          ng = normalize(cross(p1-p0, p2-p0))
-//     r7 {bits(inst), bits(prim), 0, 0}
+//     r6 {ng.xyz, bits(inst)}                                    ng = normalize(cross(p1-p0, p2-p0))
+//     r7 {area, bits(prim), 0, 0}                                read only on an emitter hit / by the ray-query kernels
 // BVH4 node (64 B, four float4; child boxes quantised to 8 bits per plane on the node's own grid, rounded outwards):
 //   {origin.xyz, scale.x} {scale.y, scale.z, qlo.x[4], qlo.y[4]} {qlo.z[4], qhi.x[4], qhi.y[4], qhi.z[4]} {child[4]}
 //   plane = origin + scale * q (byte k of a q word belongs to child k); child = index << 3 | count:
@@ -50,7 +50,7 @@ ZD f3 xyz(float4 a) { return mk3(a.x, a.y, a.z); }
 
 ZD Interaction surface_interact(const DScene &S, const Hit &h) {   // interaction.py:9-30
     const float4 *r = S.shade + 8 * (size_t)h.slot;
-    float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
+    float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];   // seven of the record's eight float4
     float w0 = 1.0f - h.u - h.v, w1 = h.u, w2 = h.v;               // Hit::interpolate
     Interaction it;
     it.p = xyz(r0) * w0 + xyz(r1) * w1 + xyz(r2) * w2;
@@ -58,7 +58,7 @@ ZD Interaction surface_interact(const DScene &S, const Hit &h) {   // interactio
     it.uv.y = w0 * r1.w + w1 * r3.w + w2 * r5.w;
     it.ns = normalize(xyz(r3) * w0 + xyz(r4) * w1 + xyz(r5) * w2);
     it.ng = xyz(r6);
-    it.inst = __float_as_int(r7.x); it.prim = __float_as_int(r7.y);
+    it.inst = __float_as_int(r6.w); it.prim = 0;                   // prim is only reported by the ray-query kernels (r7.y)
     return it;
 }
 
@@ -271,9 +271,10 @@ ZD LightSample sample_light(const DScene &S, f3 origin, float u_pick, NEXT1 next
 template <bool ENV>
 ZD float sample_light_pdf(const DScene &S, f3 origin, int inst, int slot, f3 p) {
     float4 r6 = S.shade[8 * (size_t)slot + 6];
+    float area = S.shade[8 * (size_t)slot + 7].x;
     int T = S.inst_tri_begin[inst + 1] - S.inst_tri_begin[inst];
     f3 wi; float c, d2;
-    return light_pdf(origin, p, xyz(r6), r6.w, ((ENV ? S.env_count : 0) + S.light_count) * T, wi, c, d2);
+    return light_pdf(origin, p, xyz(r6), area, ((ENV ? S.env_count : 0) + S.light_count) * T, wi, c, d2);
 }
 
 ZD float balanced_heuristic(float a, float b) { return a * rcp(fmaxf(a + b, 1e-4f)); }   // prb.py:12-13

@@ -413,9 +413,9 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
         q[3] = make_float4(r.n[0].x, r.n[0].y, r.n[0].z, r.uv[1][1]);
         q[4] = make_float4(r.n[1].x, r.n[1].y, r.n[1].z, r.uv[2][0]);
         q[5] = make_float4(r.n[2].x, r.n[2].y, r.n[2].z, r.uv[2][1]);
-        q[6] = make_float4(r.ng.x, r.ng.y, r.ng.z, r.area);
         float fi, fp; memcpy(&fi, &r.inst, 4); memcpy(&fp, &r.prim, 4);
-        q[7] = make_float4(fi, fp, 0.0f, 0.0f);
+        q[6] = make_float4(r.ng.x, r.ng.y, r.ng.z, fi);
+        q[7] = make_float4(r.area, fp, 0.0f, 0.0f);
     }
     std::vector<int32_t> lights; int light_count = 0;
     light_list(s->emission, ninst, lights, light_count);

@@ -608,7 +608,7 @@ __global__ __launch_bounds__(WAVE) void k_trace(DScene S, const float4 *rays, ui
         Hit h = A::closest(S, lds, xyz(a), xyz(b), a.w, b.w);
         if (valid) {
             int inst = -1, prim = -1;
-            if (h.slot >= 0) { float4 r7 = S.shade[8 * (size_t)h.slot + 7]; inst = __float_as_int(r7.x); prim = __float_as_int(r7.y); }
+            if (h.slot >= 0) { inst = __float_as_int(S.shade[8 * (size_t)h.slot + 6].w); prim = __float_as_int(S.shade[8 * (size_t)h.slot + 7].y); }
             out_i[2 * (size_t)i] = inst; out_i[2 * (size_t)i + 1] = prim;
             out_f[3 * (size_t)i] = h.u; out_f[3 * (size_t)i + 1] = h.v; out_f[3 * (size_t)i + 2] = (h.slot >= 0) ? h.t : b.w;
         }

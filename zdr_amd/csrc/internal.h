@@ -42,6 +42,7 @@ struct KernelIO {
     float *cells;                     // backward: (tex_h + 1) x (tex_w + 1) staging cells of 16 floats, zeroed per call
     unsigned long long *counters;     // stats variant: 8 counters
     const unsigned long long *tile_masks;   // brute-force accel: per 8x8 tile, the triangle pairs its camera rays can hit (k_tile_masks); null = all
+    int32_t tile_masks_valid;               // the masks in the buffer already belong to this camera and shard: skip k_tile_masks
     unsigned int *work_counters;      // path integrator: 8 item counters, one per XCD, zeroed before the launch (fetch_item)
     float4 *ring;                     // path integrator: one FIFO of parked camera-ray vertices per persistent workgroup (integrators.h)
 };

@@ -287,6 +287,7 @@ struct zdr_scene {
     float4 *d_env_tex = nullptr; float *d_alias_prob = nullptr, *d_env_pdf = nullptr; int32_t *d_alias_idx = nullptr;
     float4 *d_partial = nullptr; size_t partial_bytes = 0;
     unsigned long long *d_tile_masks = nullptr; size_t tile_mask_bytes = 0;   // camera-ray candidate pairs per tile (k_tile_masks)
+    float tile_mask_key[24]; bool tile_mask_key_set = false;                  // camera + shard the masks in the buffer were built for
     unsigned int *d_work_counters = nullptr;
     float4 *d_ring = nullptr; size_t ring_bytes = 0;     // primary rings of the path kernels (integrators.h)
     float *d_cells = nullptr; size_t cells_bytes = 0;       // backward staging cells, (tex_h+1) x (tex_w+1) x 16 floats
@@ -677,11 +678,18 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (masks) {
         size_t need = (size_t)R.tiles_x * R.tiles_y * sizeof(unsigned long long);
         if (need > s->tile_mask_bytes) {
-            (void)hipFree(s->d_tile_masks); s->d_tile_masks = nullptr; s->tile_mask_bytes = 0;
+            (void)hipFree(s->d_tile_masks); s->d_tile_masks = nullptr; s->tile_mask_bytes = 0; s->tile_mask_key_set = false;
             HIPCHK(hipMalloc((void **)&s->d_tile_masks, need));
             s->tile_mask_bytes = need;
         }
         io.tile_masks = s->d_tile_masks;
+        // the masks depend on the camera and the tile grid only (the geometry of a scene handle never changes):
+        // an optimisation loop that renders the same view again does not rebuild them
+        float key[24] = {(float)R.x0, (float)R.y0, (float)R.x1, (float)R.y1, (float)R.width, (float)R.height, R.two_over_w, R.two_over_h, R.aspect, R.cam_tan,
+                         R.cam_o[0], R.cam_o[1], R.cam_o[2], R.cam_fwd[0], R.cam_fwd[1], R.cam_fwd[2], R.cam_right[0], R.cam_right[1], R.cam_right[2],
+                         R.cam_upp[0], R.cam_upp[1], R.cam_upp[2], (float)R.tiles_x, (float)R.tiles_y};
+        io.tile_masks_valid = (s->tile_mask_key_set && memcmp(key, s->tile_mask_key, sizeof key) == 0) ? 1 : 0;
+        memcpy(s->tile_mask_key, key, sizeof key); s->tile_mask_key_set = true;
     }
     io.material = (const float4 *)material; io.image = (float4 *)image; io.partial = s->d_partial;
     io.d_image = (const float4 *)d_image; io.d_material = d_material; io.cells = s->d_cells; io.counters = s->d_counters;

@@ -574,7 +574,7 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     if (nblocks <= 0) return 0;
     dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
     const size_t dyn = accel_is_bvh ? (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int) : 0;
-    if (io.tile_masks)
+    if (io.tile_masks && !io.tile_masks_valid)
         hipLaunchKernelGGL(k_tile_masks, dim3(R.tiles_x * R.tiles_y), dim3(WAVE), 0, st, S, R, (unsigned long long *)io.tile_masks);
     if (C.kind == ZDR_SAMPLER_CMJ) {
         if (accel_is_bvh) launch_integ<0, BvhAccel>(integrator, grid, dyn, st, S, R, C, io, backward, stats);

@@ -223,6 +223,17 @@ def test_shards_at_odd_offsets(integrator, mat_a):
     torch.testing.assert_close(g_parts, g_full, rtol=1e-4, atol=1e-6 * float(g_full.abs().max()))
 
 
+def test_limits_are_reported_before_anything_is_launched(mat_a):
+    """INTEGRATION.md, Limits: the path kernels pack (pixel, bank, sample index) into 32 bits."""
+    from zdr_amd._native import ZdrError
+    scene = make_scene("path")
+    m = torch.from_numpy(mat_a).cuda()
+    with pytest.raises(ZdrError, match="spp above 2\\^25"):
+        scene.render_forward(m, (8, 8), (1 << 25) + 1, 0, samples=(0, 4))
+    img = scene.render_forward(m, (8, 8), 1 << 25, 0, samples=(0, 4))      # at the limit: fine (4 of 2^25 samples rendered)
+    assert torch.isfinite(img).all()
+
+
 def test_stats_match_oracle_counters(cbox_oracle, mat_a):
     scene = make_scene("path")
     m = torch.from_numpy(mat_a).cuda()

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2] at FULL size (cbox, path, 512x512, spp 256): HIP forward image and PRB gradient against the
+CPU oracle on the same seed, with the oracle's own IEEE-vs-FMA difference beside them as the fp32 floor."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import oracle
+from conftest import cbox_material_np, cbox_models
+from gpu_util import make_scene, oracle_params, image_diff_stats
+from zdr_amd import geometry
+
+W, spp, seed = 512, 256, 7
+mat = cbox_material_np()
+A = geometry.assemble(cbox_models())
+S, Sf = oracle.OracleScene.from_arrays(A), oracle.OracleScene.from_arrays(A, variant="fma")
+scene = make_scene("path")
+m = torch.from_numpy(mat).cuda()
+out = {"config": f"cbox path {W}x{W} spp {spp} seed {seed}, cboxd/cboxr textures"}
+t = time.time(); img = scene.render_forward(m, (W, W), spp, seed).cpu().numpy(); out["gpu_forward_s"] = round(time.time() - t, 3)
+p = oracle_params(scene, W, W, spp, seed, mat.shape[:2])
+t = time.time(); ref = S.render_forward(p, mat); out["oracle_forward_s"] = round(time.time() - t, 1)
+flo = Sf.render_forward(p, mat)
+out["image"] = {"gpu_vs_oracle": image_diff_stats(img[..., :3], ref[..., :3]), "oracle_fma_vs_ieee": image_diff_stats(flo[..., :3], ref[..., :3])}
+cot = np.random.default_rng(1).uniform(0.5, 1.5, (W, W, 4)).astype(np.float32)
+g = torch.zeros_like(m); scene.render_backward(torch.from_numpy(cot).cuda(), g, m, (W, W), spp, seed); g = g.cpu().numpy().astype(np.float64)
+pb = oracle_params(scene, W, W, spp, seed + 1, mat.shape[:2])
+t = time.time(); gref = S.render_backward(pb, cot, mat).astype(np.float64); out["oracle_backward_s"] = round(time.time() - t, 1)
+gflo = Sf.render_backward(pb, cot, mat).astype(np.float64)
+def gstats(a, b):
+    return {"rel_l1": float(np.abs(a - b).sum() / np.abs(b).sum()), "sum_rel": float(abs(a.sum() - b.sum()) / abs(b.sum())),
+            "max_abs_over_max": float(np.abs(a - b).max() / np.abs(b).max()), "nnz": int((a != 0).sum()), "nnz_ref": int((b != 0).sum())}
+out["gradient"] = {"gpu_vs_oracle": gstats(g, gref), "oracle_fma_vs_ieee": gstats(gflo, gref)}
+print(json.dumps(out, indent=1))
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "full_size_parity.json"), "w"), indent=1)

@@ -17,12 +17,15 @@ __global__ __launch_bounds__(64) void k(float *buf, uint32_t ncells_mask, int it
     for (int i = 0; i < iters; i++) {
         seed = hash32(seed + i);
         uint32_t cell;
-        if (SHAPE == 0 || SHAPE == 3) cell = hash32(seed + (lane >> 4)) & ncells_mask;
+        if (SHAPE == 0 || SHAPE >= 3) cell = hash32(seed + (lane >> 4)) & ncells_mask;
         else if (SHAPE == 1) cell = hash32(seed + lane) & ncells_mask;
         else cell = (hash32(seed) & ncells_mask) & ~3u;
         float *p = buf + 16 * (size_t)cell + ((SHAPE == 1) ? 0 : (SHAPE == 2 ? lane : (lane & 15)));
         if (SHAPE == 3 && (lane & 15) >= 4) continue;
-        unsafeAtomicAdd(p, 1.0f);
+        if (SHAPE == 4) __hip_atomic_fetch_add(p, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // as shape 0, workgroup scope
+        else if (SHAPE == 5) __hip_atomic_fetch_add(p, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // as shape 0, wavefront scope
+        else if (SHAPE == 6) __hip_atomic_fetch_add(p, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // as shape 0, system scope
+        else unsafeAtomicAdd(p, 1.0f);
     }
 }
 
@@ -48,5 +51,8 @@ int main() {
     run<3>("4 cells x 4 floats per instruction", buf, ncells, 16);
     run<1>("64 cells x 1 float per instruction", buf, ncells, 64);
     run<2>("1 block x 64 floats per instruction", buf, ncells, 64);
+    run<4>("4 cells x 16 floats, WORKGROUP scope", buf, ncells, 64);
+    run<5>("4 cells x 16 floats, WAVEFRONT scope", buf, ncells, 64);
+    run<6>("4 cells x 16 floats, SYSTEM scope", buf, ncells, 64);
     return 0;
 }

@@ -10,7 +10,9 @@
  *
  * All functions return 0 on success or a negative ZDR_E_* code; zdr_last_error() gives the
  * thread-local message.  One in-flight call per scene handle (render.py:216-222: the
- * reference scene is not re-entrant either).
+ * reference scene is not re-entrant either) — the handle owns per-call workspaces (staging cells, chunk
+ * partials, work counters, the parked-vertex FIFOs), so two renders of ONE scene must not overlap, not even on
+ * different streams: enqueue them on one stream, or use one scene handle per stream.
  */
 #ifndef ZDR_H
 #define ZDR_H
@@ -116,6 +118,15 @@ int zdr_render_backward(zdr_scene *scene, const zdr_render_params *params, const
  * shadow rays, shaded vertices, emitter hits via BSDF sampling, NaN-dropped samples, 0. */
 int zdr_render_stats(zdr_scene *scene, const zdr_render_params *params, const float *material,
                      uint64_t counters[8], void *stream);
+
+/* The kernels carry watchdogs that can end work early instead of spinning on the GPU (a persistent wave that makes
+ * no progress; a BVH walk past its iteration budget).  They never trip on valid inputs; if one does it sets a sticky
+ * bit in a device error word, and the images / gradients produced since the last check are INCOMPLETE.
+ * zdr_scene_check synchronises `stream`, returns ZDR_E_HIP (message in zdr_last_error) if the word is set, and
+ * clears it.  zdr_render_stats checks by itself; with the environment variable ZDR_CHECK=1 every render call does
+ * (one synchronise per call).  The reference has no counterpart: LuisaCompute raises from luisa.synchronize()
+ * (render.py:172,198). */
+int zdr_scene_check(zdr_scene *scene, void *stream);
 
 /* LuisaCompute Accel.trace_closest / trace_any (prb.py:25,59) as batch queries, for testing the
  * acceleration structure.  DEVICE rays: n x 8 {o[3], tmin, d[3], tmax}.

@@ -128,3 +128,51 @@ def test_hip_environment_only_scene_matches_oracle(sky_tables):
     Sf = oracle.OracleScene.from_arrays(geometry.assemble(models), variant="fma"); Sf.set_envmap(I, prob, alias, pdf)
     p = oracle_params(scene, 64, 64, 16, 1, mat.shape[:2])
     assert_image_parity(img[..., :3], S.render_forward(p, mat)[..., :3], "envmap only", floor=Sf.render_forward(p, mat)[..., :3])
+
+
+@pytest.mark.gpu
+def test_environment_and_pmj02bn_tables_are_independent_state(cbox_arrays, sky_tables):
+    """render.py:150-156 (add_envmap) and pmj02bn.py:9-18 (sampler tables) are independent state of a scene: setting
+    the sampler tables after the environment must leave the environment buffers alone (round 1 freed them), in
+    either order, and each buffer is released exactly once (its setter or zdr_scene_destroy)."""
+    import ctypes as C
+    import torch
+    from gpu_util import assert_grad_parity, assert_image_parity, make_scene, oracle_params
+    from zdr_amd import pmj02bn_tables as T
+    I, prob, alias, pdf = sky_tables
+    pmj = T.pmj02_sets(n_sets=5, n_samples=256, seed=2)
+    bn = T.blue_noise_textures(n_tex=4, res=32, seed=2)
+    oracle.lib().zdro_set_pmj02bn_tables(pmj.ctypes.data_as(C.POINTER(C.c_uint32)), 5, 256, bn.ctypes.data_as(C.POINTER(C.c_uint16)), 4, 32)
+    S = oracle.OracleScene.from_arrays(cbox_arrays); Sf = oracle.OracleScene.from_arrays(cbox_arrays, variant="fma")
+    S.set_envmap(I, prob, alias, pdf); Sf.set_envmap(I, prob, alias, pdf)
+    oracle.lib("fma").zdro_set_pmj02bn_tables(pmj.ctypes.data_as(C.POINTER(C.c_uint32)), 5, 256, bn.ctypes.data_as(C.POINTER(C.c_uint16)), 4, 32)
+    mat = fd_material_np(256, 0)
+    W, spp = 64, 16
+    ones = np.ones((W, W, 4), np.float32)
+    for order in ("env_first", "tables_first"):
+        scene = make_scene("path")
+        scene.sampler = "pmj02bn"
+        if order == "env_first":
+            scene.add_envmap(sun_sky())
+            scene.set_pmj02bn_tables(pmj, bn)            # round 1: this call freed the environment buffers
+        else:
+            scene.set_pmj02bn_tables(pmj, bn)
+            scene.add_envmap(sun_sky())
+        m = torch.from_numpy(mat).cuda().requires_grad_()
+        img = scene.render(m, res=(W, W), spp=spp, seed=4)
+        img.sum().backward()
+        p = oracle_params(scene, W, W, spp, 4, mat.shape[:2], sampler=oracle.SAMPLER_PMJ02BN)
+        pb = oracle_params(scene, W, W, spp, 5, mat.shape[:2], sampler=oracle.SAMPLER_PMJ02BN)
+        assert_image_parity(img.detach().cpu().numpy()[..., :3], S.render_forward(p, mat)[..., :3], f"envmap + pmj02bn forward ({order})",
+                            floor=Sf.render_forward(p, mat)[..., :3], n_paths=W * W * spp)
+        assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, ones, mat), f"envmap + pmj02bn backward ({order})",
+                           floor=Sf.render_backward(pb, ones, mat), n_paths=W * W * spp)
+        # new tables while an environment is set, then render again: the environment is still there
+        scene.set_pmj02bn_tables(pmj, bn)
+        again = scene.render(m.detach(), res=(W, W), spp=spp, seed=4)
+        assert torch.equal(again, img.detach())
+        scene.add_envmap(None)
+        dark = scene.render(m.detach(), res=(32, 32), spp=4, seed=1)
+        assert torch.isfinite(dark).all()
+        del scene                                        # zdr_scene_destroy: every buffer freed once
+        torch.cuda.synchronize()

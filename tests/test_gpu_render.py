@@ -312,3 +312,27 @@ def test_render_duvdxy_matches_oracle(cbox_oracle, mat_a):
     d = np.abs(got - ref)
     # pixels whose primary ray grazes a triangle edge may pick the neighbouring triangle
     assert (d > 1e-5 + 1e-3 * np.abs(ref)).mean() < 2e-3, (d.max(), (d > 1e-5 + 1e-3 * np.abs(ref)).mean())
+
+
+def test_a_tripped_watchdog_is_reported_not_swallowed(mat_a, monkeypatch):
+    """The BVH walk and the persistent path loop carry watchdogs that end work instead of spinning.  If one trips,
+    the device error word makes the next check fail (zdr_scene_check, zdr_render_stats, or every call under
+    ZDR_CHECK=1) — an incomplete image never comes back as ZDR_OK with nothing said.  The walk budget is forced to
+    three iterations here (ZDR_DEBUG_BVH_BUDGET); a normal scene reports nothing."""
+    from zdr_amd._native import ZdrError
+    m = torch.from_numpy(mat_a).cuda()
+    good = make_scene("path", accel="bvh")
+    good.render_forward(m, (32, 32), 4, 0)
+    good.check()                                                  # nothing tripped
+    monkeypatch.setenv("ZDR_DEBUG_BVH_BUDGET", "3")
+    bad = make_scene("path", accel="bvh")
+    monkeypatch.delenv("ZDR_DEBUG_BVH_BUDGET")
+    img = bad.render_forward(m, (32, 32), 4, 0)
+    assert torch.isfinite(img).all()                              # zero-filled, never uninitialised memory
+    with pytest.raises(ZdrError, match="BVH walk exceeded its iteration budget"):
+        bad.check()
+    bad.check()                                                   # reading the word clears it
+    g = torch.zeros_like(m)
+    bad.render_backward(torch.ones((32, 32, 4), device="cuda"), g, m, (32, 32), 4, 0)
+    with pytest.raises(ZdrError, match="incomplete"):
+        bad.render_stats(m, (32, 32), 4)                          # the stats call checks by itself

@@ -205,7 +205,7 @@ struct BvhAccel {
         int id = 0, cnt = root_cnt;
         // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it
         // impossible for a wave to spin forever whatever the node data or the ray (NaNs) look like.
-        const int budget0 = 2 * (S.nnodes + S.ntris) + 8;
+        const int budget0 = (S.debug_bvh_budget > 0) ? S.debug_bvh_budget : 2 * (S.nnodes + S.ntris) + 8;
         int budget = budget0;
         for (;;) {
             bool ray_done = (--budget < 0);
@@ -270,6 +270,7 @@ struct BvhAccel {
             if (HAS_A && first) {
                 occ = h.slot >= 0;
                 if (!HAS_B || !needB) break;
+                if (budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);
                 first = false;
                 o = oB; d = dB; tmin = tminB; inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
                 h.slot = -1; h.t = tmaxB;
@@ -278,6 +279,7 @@ struct BvhAccel {
             }
             break;
         }
+        if (budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);   // the walk was cut short: whatever it returns is not a result
         if (HAS_B && !first && needB) { hit = h; hit_barycentrics(S, hit, oB, dB); }
     }
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {

@@ -38,7 +38,14 @@ struct DScene {
     const float4 *env_tex; const float *alias_prob; const int32_t *alias_idx; const float *env_pdf;
     int32_t env_count, env_h, env_w, map_w, map_h;
     int32_t stack_entries;          // per-lane traversal stack entries this tree needs (dynamic LDS: min(entries, ZDR_BVH_LDS_STACK) x 64 ints per wave)
+    // Device error word (sticky until the host reads it: zdr_scene_check, zdr_render_stats, ZDR_CHECK=1).  A watchdog
+    // that ends work early ORs its bit in, so an incomplete image or gradient can never pass as a good one.
+    unsigned int *error_word;
+    int32_t debug_bvh_budget;       // > 0: iteration budget of every BVH walk (env ZDR_DEBUG_BVH_BUDGET at scene creation) — lets a test trip the watchdog
 };
+#define ZDR_DEVERR_STALL 1u          // a persistent path wave left its loop without having drained its work
+#define ZDR_DEVERR_BVH_BUDGET 2u     // a BVH walk ran out of its iteration budget (corrupt nodes or a NaN ray that never ends)
+ZD void raise_device_error(const DScene &S, unsigned int bit) { if (S.error_word) atomicOr(S.error_word, bit); }
 
 struct Hit { int slot; float u, v, t; };   // slot < 0: miss (LuisaCompute Hit{inst, prim, bary, ray_t})
 

@@ -292,6 +292,7 @@ struct zdr_scene {
     float4 *d_ring = nullptr; size_t ring_bytes = 0;     // primary rings of the path kernels (integrators.h)
     float *d_cells = nullptr; size_t cells_bytes = 0;       // backward staging cells, (tex_h+1) x (tex_w+1) x 16 floats
     unsigned long long *d_counters = nullptr;
+    unsigned int *d_error = nullptr;                        // device error word (scene.h, ZDR_DEVERR_*), sticky until read
     uint64_t device_bytes = 0;
     DScene ds{};
 };
@@ -450,9 +451,13 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     up(&s->d_inst_tri_begin, s->inst_tri_begin.data(), s->inst_tri_begin.size() * sizeof(int32_t));
     up(&s->d_slot_of_tri, slot_of_tri.data(), slot_of_tri.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_error, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(s->d_error, 0, sizeof(unsigned int));
     if (e != hipSuccess) { std::string m = hipGetErrorString(e); zdr_scene_destroy(s); return fail(ZDR_E_HIP, "scene upload: " + m); }
     s->ds.isect = s->d_isect; s->ds.pairs = s->d_pairs; s->ds.shade = s->d_shade; s->ds.nodes = s->d_nodes; s->ds.emission = s->d_emission;
     s->ds.light_insts = s->d_light_insts; s->ds.inst_tri_begin = s->d_inst_tri_begin; s->ds.slot_of_tri = s->d_slot_of_tri;
+    s->ds.error_word = s->d_error;
+    if (const char *e = getenv("ZDR_DEBUG_BVH_BUDGET")) s->ds.debug_bvh_budget = atoi(e);
     s->ds.ntris = (int32_t)ntris; s->ds.ninst = (int32_t)ninst; s->ds.light_count = light_count; s->ds.nnodes = (int32_t)s->bvh_nodes; s->ds.stack_entries = (int32_t)s->stack_entries;
     { int rc = upload_light_table(s, lights, light_count, nullptr); if (rc) { zdr_scene_destroy(s); return rc; } }
     *out = s;
@@ -485,7 +490,7 @@ extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts); (void)hipFree(s->d_light_tris); (void)hipFree(s->d_light_range); (void)hipFree(s->d_emission4);
-    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters);
+    (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters); (void)hipFree(s->d_error);
     delete s;
     return ZDR_OK;
 }
@@ -542,7 +547,10 @@ extern "C" int zdr_scene_set_pmj02bn_tables(zdr_scene *s, const uint32_t *pmj, u
                                             const uint16_t *bn, uint32_t ntex, uint32_t bnres) {
     if (!s || !pmj || !bn || !nsets || !nsamples || !ntex || !bnres) return fail(ZDR_E_INVALID, "bad table arguments");
     HIPCHK(hipSetDevice(s->device));
-    (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); s->d_pmj = nullptr; s->d_bn = nullptr;
+    HIPCHK(hipDeviceSynchronize());     // nothing in flight may still read the old tables
+    // only the sampler tables belong to this setter (the environment buffers are zdr_scene_set_envmap's)
+    (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); s->d_pmj = nullptr; s->d_bn = nullptr;
+    memset(&s->tab, 0, sizeof s->tab);
     HIPCHK(upload(&s->d_pmj, pmj, (size_t)nsets * nsamples * 2 * sizeof(uint32_t), &s->device_bytes));
     HIPCHK(upload(&s->d_bn, bn, (size_t)ntex * bnres * bnres * sizeof(uint16_t), &s->device_bytes));
     s->tab.pmj = s->d_pmj; s->tab.bn = s->d_bn; s->tab.nsets = nsets; s->tab.nsamples = nsamples; s->tab.ntex = ntex; s->tab.bnres = bnres;
@@ -658,6 +666,27 @@ static int ensure_cells(zdr_scene *s, const RenderCfg &R, hipStream_t st) {
     return ZDR_OK;
 }
 
+// Reads (and clears) the device error word; the stream is synchronised first.  A set bit means a watchdog ended
+// work early (zdr_kernels.hip: stall; accel.h: BVH budget): the image / gradient of the calls since the last
+// check is incomplete.
+static int check_device_error(zdr_scene *s, hipStream_t st) {
+    unsigned int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, s->d_error, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!h) return ZDR_OK;
+    HIPCHK(hipMemsetAsync(s->d_error, 0, sizeof h, st));
+    std::string m = "device watchdog tripped:";
+    if (h & ZDR_DEVERR_STALL) m += " a persistent path wave stopped without draining its work items;";
+    if (h & ZDR_DEVERR_BVH_BUDGET) m += " a BVH walk exceeded its iteration budget;";
+    return fail(ZDR_E_HIP, m + " results since the last check are incomplete");
+}
+
+extern "C" int zdr_scene_check(zdr_scene *s, void *stream) {
+    if (!s) return fail(ZDR_E_INVALID, "null scene");
+    HIPCHK(hipSetDevice(s->device));
+    return check_device_error(s, (hipStream_t)stream);
+}
+
 static int render_common(zdr_scene *s, const zdr_render_params *p, const float *material, float *image, const float *d_image,
                          float *d_material, int backward, int stats, void *stream) {
     if (!s || !p || !material) return fail(ZDR_E_INVALID, "null argument");
@@ -702,6 +731,8 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (stats && p->integrator == ZDR_UVGRAD) return fail(ZDR_E_UNSUPPORTED, "no statistics for render_duvdxy");
     if (zdr_launch_render(s->ds, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
         return fail(ZDR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(hipGetLastError()));
+    static const bool check_every_call = getenv("ZDR_CHECK") && atoi(getenv("ZDR_CHECK")) != 0;   // opt-in: costs a synchronise per call
+    if (check_every_call && !stats) return check_device_error(s, (hipStream_t)stream);
     return ZDR_OK;
 }
 
@@ -726,7 +757,7 @@ extern "C" int zdr_render_stats(zdr_scene *s, const zdr_render_params *p, const 
     HIPCHK(hipMemcpyAsync(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < 8; i++) counters[i] = h[i];
-    return ZDR_OK;
+    return check_device_error(s, st);
 }
 
 extern "C" int zdr_trace_closest(zdr_scene *s, const float *rays, uint32_t n, int32_t *inst_prim, float *bary_t, void *stream) {

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesFwd) void k_path(DScene S, Render
         }
         if (__ballot(alive) == 0ull && q.tail == q.head && next_sample >= s_end && !more_items) break;   // both banks are retired by now
         stall = progress ? 0 : stall + 1;
-        if (stall > 4) break;                               // cannot happen (every branch above makes progress); never spin on the GPU
+        if (stall > 4) { raise_device_error(S, ZDR_DEVERR_STALL); break; }   // cannot happen (every branch above makes progress); never spin on the GPU, never end silently
     }
     flush_counters<STATS>(io, cnt);
 }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             if (ib.logical[b] >= 0 && ib.inflight[b] == 0 && (b != bank || next_sample >= s_end)) ib.logical[b] = -1;
         if (__ballot(alive) == 0ull && pq.tail == pq.head && next_sample >= s_end && !more_items) break;
         stall = progress ? 0 : stall + 1;
-        if (stall > 4) break;                               // cannot happen (every branch above makes progress); never spin on the GPU
+        if (stall > 4) { raise_device_error(S, ZDR_DEVERR_STALL); break; }   // cannot happen (every branch above makes progress); never spin on the GPU, never end silently
     }
     scatter_flush(q, io.cells);
 }

@@ -149,9 +149,8 @@ class Scene:
         is written (other pixels of ``out`` keep their value; a fresh image is zero-filled)."""
         self._check_material(material)
         material = material.detach().contiguous()
-        if out is None:
-            full = rect is None
-            image = (torch.empty if full else torch.zeros)((res[1], res[0], 4), dtype=torch.float32, device=self.device)
+        if out is None:   # zero-filled even when the call covers every pixel: a dropped work item must never surface as uninitialised memory
+            image = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=self.device)
         else:
             image = out
         p = self._params(res, spp, seed, material.shape[0:2], rect, samples, integrator=kernel)
@@ -210,6 +209,11 @@ class Scene:
         reference drives this kernel with LuisaCompute's own random sampler (uvgrad.py:82, third-party);
         here the scene's sampler provides the pixel jitter."""
         return self.render_forward(material.detach(), res, spp, seed, kernel=N.UVGRAD)
+
+    def check(self):
+        """Synchronises and raises ZdrError if a device watchdog ended work early since the last check
+        (include/zdr.h, zdr_scene_check).  LuisaCompute raises from luisa.synchronize() (render.py:172,198)."""
+        N.check(N.lib().zdr_scene_check(self._handle, self._stream()))
 
     # ------------------------------------------------------------------- test / debug hooks
     def trace_closest(self, rays):

@@ -55,6 +55,11 @@ typedef struct {
     int32_t max_depth, rr_depth;       /* prb.py:15-16: 16, 2 */
     zdr_camera camera;
     int32_t tex_h, tex_w;              /* material tensor is (tex_h, tex_w, 4) float32 */
+    /* Interleaved pixel-tile shard (BASELINE configs[3] "pixel-tiled across 8 GPUs"): the rectangle is cut
+     * into 8x8 tiles numbered row-major from its own corner, and this call renders the tiles whose number is
+     * congruent to tile_shard_index modulo tile_shard_count — one launch per rank, every rank sees every part of the
+     * image (load balance).  tile_shard_count <= 1: the whole rectangle. */
+    int32_t tile_shard_index, tile_shard_count;
 } zdr_render_params;
 
 typedef struct {

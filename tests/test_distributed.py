@@ -20,16 +20,28 @@ def _oracle_renderer(mode):
     from zdr_amd import geometry
     S = oracle.OracleScene.from_arrays(geometry.assemble(cbox_models()))
 
-    def fwd(material, res, spp, seed, rect, samples, out):
-        p = oracle.make_params("path", res[0], res[1], spp, seed, CBOX_CAMERA, tuple(material.shape[:2]), rect=rect, samples=samples, nthreads=2)
-        img = torch.from_numpy(S.render_forward(p, material.numpy()))
+    def tiles_of(rect, tile_shard):
+        # the oracle knows rectangles only: an interleaved tile shard (include/zdr.h) is the list of its 8x8 tiles
+        if tile_shard is None:
+            return [rect]
         x0, y0, x1, y1 = rect
-        out[y0:y1, x0:x1] = img[y0:y1, x0:x1]
+        index, count = tile_shard
+        tx = (x1 - x0 + 7) // 8; ty = (y1 - y0 + 7) // 8
+        return [(x0 + 8 * (t % tx), y0 + 8 * (t // tx), min(x0 + 8 * (t % tx) + 8, x1), min(y0 + 8 * (t // tx) + 8, y1))
+                for t in range(index, tx * ty, count)]
+
+    def fwd(material, res, spp, seed, rect, samples, out, tile_shard=None):
+        for r in tiles_of(rect, tile_shard):
+            p = oracle.make_params("path", res[0], res[1], spp, seed, CBOX_CAMERA, tuple(material.shape[:2]), rect=r, samples=samples, nthreads=2)
+            img = torch.from_numpy(S.render_forward(p, material.numpy()))
+            x0, y0, x1, y1 = r
+            out[y0:y1, x0:x1] = img[y0:y1, x0:x1]
         return out
 
-    def bwd(grad_output, d_material, material, res, spp, seed, rect, samples):
-        p = oracle.make_params("path", res[0], res[1], spp, seed + 1, CBOX_CAMERA, tuple(material.shape[:2]), rect=rect, samples=samples, nthreads=2)
-        d_material += torch.from_numpy(S.render_backward(p, grad_output.numpy(), material.numpy()))
+    def bwd(grad_output, d_material, material, res, spp, seed, rect, samples, tile_shard=None):
+        for r in tiles_of(rect, tile_shard):
+            p = oracle.make_params("path", res[0], res[1], spp, seed + 1, CBOX_CAMERA, tuple(material.shape[:2]), rect=r, samples=samples, nthreads=2)
+            d_material += torch.from_numpy(S.render_backward(p, grad_output.numpy(), material.numpy()))
 
     return zd.ShardedRenderer(fwd, bwd, mode)
 
@@ -51,7 +63,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("mode", ["rows", "samples", "seeds"])
+@pytest.mark.parametrize("mode", ["tiles", "rows", "samples", "seeds"])
 def test_two_ranks_reproduce_the_single_process_render(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -77,7 +89,7 @@ def test_two_ranks_reproduce_the_single_process_render(mode):
         ref_img, ref_grad = 0.5 * (a[0] + b[0]), 0.5 * (a[1] + b[1])
     else:
         ref_img, ref_grad = single(SEED)
-    if mode == "rows":
+    if mode in ("rows", "tiles"):
         assert np.array_equal(img, ref_img)                     # pixel tiles: bit-identical union
     else:
         np.testing.assert_allclose(img, ref_img, rtol=1e-5, atol=1e-6)
@@ -94,4 +106,7 @@ def test_shard_plans_cover_the_work_exactly():
             b, e = zd.plan("samples", r, world, (512, 512), 256, 0).samples
             samples[b:e] += 1
         assert (rows == 1).all() and (samples == 1).all()
+        shards = [zd.plan("tiles", r, world, (512, 512), 256, 0) for r in range(world)]
+        assert all(s.rects == [(0, 0, 512, 512)] and s.samples == (0, 256) for s in shards)
+        assert [s.tile_shard for s in shards] == ([None] if world == 1 else [(r, world) for r in range(world)])
     assert len({zd.plan("seeds", r, 8, (8, 8), 4, 5).seed for r in range(8)}) == 8

@@ -38,6 +38,7 @@ class RenderParams(C.Structure):
         ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
         ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
         ("camera", CameraPOD), ("tex_h", C.c_int32), ("tex_w", C.c_int32),
+        ("tile_shard_index", C.c_int32), ("tile_shard_count", C.c_int32),
     ]
 
 

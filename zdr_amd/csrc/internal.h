@@ -24,6 +24,7 @@ struct RenderCfg {
     uint32_t sample_begin, sample_end;
     uint32_t chunk;                   // samples per wave: chunk c covers [begin + c*chunk, ...)
     int32_t nchunks, tiles_x, tiles_y;
+    int32_t shard_index, shard_count, ntiles;   // interleaved tile shard: tiles index, index + count, ... ; ntiles = how many that is
     int32_t use_tent, max_depth, rr_depth;
     int32_t tex_h, tex_w;
     float two_over_w, two_over_h, aspect;      // integrator.py:22-23
@@ -36,7 +37,7 @@ struct RenderCfg {
 struct KernelIO {
     const float4 *material;           // (tex_h, tex_w) float4
     float4 *image;                    // (H, W) float4
-    float4 *partial;                  // nchunks x (H*W) float4 scratch when nchunks > 1
+    float4 *partial;                  // scratch when nchunks > 1: [chunk][tile of the shard][lane] float4 (one 1 KiB line per wave)
     const float4 *d_image;            // backward: cotangent
     float *d_material;                // backward: += gathered from the staging cells by k_cells_to_grad
     float *cells;                     // backward: (tex_h + 1) x (tex_w + 1) staging cells of 16 floats, zeroed per call

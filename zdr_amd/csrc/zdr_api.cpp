@@ -591,6 +591,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     if (p->sample_begin > p->sample_end || p->sample_end > p->spp) return fail(ZDR_E_INVALID, "bad sample range");
     if (p->tex_h <= 0 || p->tex_w <= 0) return fail(ZDR_E_INVALID, "bad texture size");
     if (p->max_depth < 1) return fail(ZDR_E_INVALID, "max_depth must be >= 1");
+    if (p->tile_shard_count > 1 && (p->tile_shard_index < 0 || p->tile_shard_index >= p->tile_shard_count)) return fail(ZDR_E_INVALID, "tile_shard_index must lie in [0, tile_shard_count)");
     if (backward && p->integrator == ZDR_PATH && p->max_depth > ZDR_MAX_RECORDED_DEPTH) return fail(ZDR_E_UNSUPPORTED, "path backward records at most 16 vertices (prb.py:15)");
     memset(&R, 0, sizeof R);
     R.width = p->width; R.height = p->height; R.x0 = p->x0; R.y0 = p->y0; R.x1 = p->x1; R.y1 = p->y1;
@@ -615,7 +616,11 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     // 256 CUs x 4 SIMDs busy with several waves each and to let the dispatcher balance uneven tiles
     R.tiles_x = (p->x1 - p->x0 + 7) / 8; R.tiles_y = (p->y1 - p->y0 + 7) / 8;
     uint32_t ns = p->sample_end - p->sample_begin;
-    long tiles = (long)R.tiles_x * R.tiles_y;
+    R.shard_count = p->tile_shard_count > 1 ? p->tile_shard_count : 1;
+    R.shard_index = p->tile_shard_count > 1 ? p->tile_shard_index : 0;
+    const long all_tiles = (long)R.tiles_x * R.tiles_y;
+    R.ntiles = (int32_t)(all_tiles > R.shard_index ? (all_tiles - R.shard_index + R.shard_count - 1) / R.shard_count : 0);
+    long tiles = R.ntiles;
     long target_waves = 65536;            // work items (tile x sample chunk) the persistent waves draw; cbox 512^2 spp 256: 16384 11.3/18.5 ms, 32768 10.7/17.7, 65536 10.25/17.2, 131072 10.2/17.1
     if (const char *e = getenv("ZDR_TARGET_WAVES")) target_waves = std::max(1L, atol(e));
     uint32_t min_chunk = 16;
@@ -632,7 +637,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
 
 static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
     if (R.nchunks <= 1) return ZDR_OK;
-    size_t need = (size_t)R.nchunks * (size_t)(R.x1 - R.x0) * (size_t)(R.y1 - R.y0) * sizeof(float4);   // the shard rectangle only
+    size_t need = (size_t)R.nchunks * (size_t)R.ntiles * 64 * sizeof(float4);   // [chunk][tile of the shard][lane]
     if (need > s->partial_bytes) {
         (void)hipFree(s->d_partial); s->d_partial = nullptr; s->partial_bytes = 0;
         HIPCHK(hipMalloc((void **)&s->d_partial, need));

@@ -17,16 +17,17 @@
 // __launch_bounds__ second argument = minimum waves per SIMD (caps the VGPR budget at 512 / n).
 // Measured on cbox 512^2 spp 256 (profiles/r1_ab_flags.txt): 3 (<= 168 VGPRs, no spills) is best for both.
 
-struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk, tile; };
+struct WorkItem { int x, y, pix; bool valid; uint32_t s_begin, s_end; int chunk, tile, tile_local; };   // tile: number within the rectangle; tile_local: within this call's shard
 
 // Work item `logical` = (tile, sample chunk); consecutive items are the chunks of one tile, then the next tile.
 ZD WorkItem decode_item(const RenderCfg &R, int logical) {
-    const int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
+    const int nblocks = R.ntiles * R.nchunks;
     WorkItem w;
     w.valid = logical >= 0 && logical < nblocks;
-    const int tile = w.valid ? logical / R.nchunks : 0;
-    w.chunk = w.valid ? logical - tile * R.nchunks : 0;
-    w.tile = tile;
+    const int tl = w.valid ? logical / R.nchunks : 0;
+    w.chunk = w.valid ? logical - tl * R.nchunks : 0;
+    const int tile = tl * R.shard_count + R.shard_index;     // interleaved tile shard (zdr.h)
+    w.tile = tile; w.tile_local = tl;
     const int ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
     const int lane = threadIdx.x;
     w.x = R.x0 + tx * 8 + (lane & 7);
@@ -41,7 +42,7 @@ ZD WorkItem decode_item(const RenderCfg &R, int logical) {
 
 // one workgroup per item (direct / collocated / uvgrad kernels): XCD-contiguous tile runs
 ZD WorkItem decode_block(const RenderCfg &R) {
-    const int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
+    const int nblocks = R.ntiles * R.nchunks;
     const int per_xcd = (nblocks + 7) >> 3;
     const int b = blockIdx.x;
     const int logical = (b & 7) * per_xcd + (b >> 3);
@@ -53,7 +54,7 @@ ZD WorkItem decode_block(const RenderCfg &R) {
 // footprints of neighbouring tiles share that XCD's L2; when its own run is used up it takes from the others.
 // Wave-uniform; returns -1 when no item is left.  Counters only grow, by at most 8 per call.
 ZD int fetch_item(const RenderCfg &R, unsigned int *counters) {
-    const int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
+    const int nblocks = R.ntiles * R.nchunks;
     const int per_xcd = (nblocks + 7) >> 3;
     int got = -1;
     if (threadIdx.x == 0) {
@@ -81,9 +82,8 @@ ZD void store_pixel(const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
         float fs = (float)C.spp;
         io.image[w.pix] = make_float4(__fdiv_rn(sum.x, fs), __fdiv_rn(sum.y, fs), __fdiv_rn(sum.z, fs), R.alpha);
     } else {
-        // chunk partials cover the shard rectangle only: [chunk][y - y0][x - x0]
-        const size_t rw = (size_t)(R.x1 - R.x0), rh = (size_t)(R.y1 - R.y0);
-        io.partial[(size_t)w.chunk * (rw * rh) + (size_t)(w.y - R.y0) * rw + (size_t)(w.x - R.x0)] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        // chunk partials: [chunk][tile of this shard][lane] — a wave writes one contiguous 1 KiB line
+        io.partial[((size_t)w.chunk * R.ntiles + w.tile_local) * WAVE + threadIdx.x] = make_float4(sum.x, sum.y, sum.z, 0.0f);
     }
 }
 
@@ -500,9 +500,11 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
     int x = R.x0 + blockIdx.x * blockDim.x + threadIdx.x, y = R.y0 + blockIdx.y;
     if (x >= R.x1 || y >= R.y1) return;
     const size_t pix = (size_t)x + (size_t)y * R.width;
-    const size_t rw = (size_t)(R.x1 - R.x0), npix = rw * (size_t)(R.y1 - R.y0), rpix = (size_t)(y - R.y0) * rw + (size_t)(x - R.x0);
+    const int lx = x - R.x0, ly = y - R.y0, tile = (ly >> 3) * R.tiles_x + (lx >> 3);
+    if (tile % R.shard_count != R.shard_index) return;      // another shard's pixel: untouched
+    const size_t slot = (size_t)(tile / R.shard_count) * 64 + (size_t)((ly & 7) * 8 + (lx & 7));
     f3 s = mk3(0.0f);
-    for (int c = 0; c < R.nchunks; c++) { float4 p = partial[(size_t)c * npix + rpix]; s = s + mk3(p.x, p.y, p.z); }
+    for (int c = 0; c < R.nchunks; c++) { float4 p = partial[(size_t)c * R.ntiles * 64 + slot]; s = s + mk3(p.x, p.y, p.z); }
     float fs = (float)spp;
     image[pix] = make_float4(__fdiv_rn(s.x, fs), __fdiv_rn(s.y, fs), __fdiv_rn(s.z, fs), R.alpha);
 }
@@ -563,14 +565,14 @@ static void launch_simple(dim3 grid, size_t dyn, hipStream_t st, const DScene &S
 template <int SK, class A>
 static void launch_integ(int integrator, dim3 grid, size_t dyn, hipStream_t st, const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int backward, int stats) {
     if (integrator == ZDR_UVGRAD) hipLaunchKernelGGL((k_uvgrad<SK, A>), grid, dim3(WAVE), dyn, st, S, R, C, io);
-    else if (integrator == ZDR_PATH) launch_path<SK, A>(R.tiles_x * R.tiles_y * R.nchunks, dyn, st, S, R, C, io, backward, stats);
+    else if (integrator == ZDR_PATH) launch_path<SK, A>(R.ntiles * R.nchunks, dyn, st, S, R, C, io, backward, stats);
     else if (integrator == ZDR_DIRECT) launch_simple<ZDR_DIRECT, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
     else launch_simple<ZDR_COLLOCATED, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
 }
 
 int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
                       int integrator, int accel_is_bvh, int backward, int stats, hipStream_t st) {
-    int nblocks = R.tiles_x * R.tiles_y * R.nchunks;
+    int nblocks = R.ntiles * R.nchunks;
     if (nblocks <= 0) return 0;
     dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
     const size_t dyn = accel_is_bvh ? (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int) : 0;

@@ -6,7 +6,9 @@ and of the material gradient — an all_reduce over RCCL/xGMI (``b
 ROCm).  Payloads are small (16 MiB each at 1024^2), far below what the render itself costs.
 
 Shard modes
-  "rows"     pixel tiles: interleaved bands of rows; union is bit-identical to the unsharded image
+  "tiles"    pixel tiles: the 8x8 tiles of the image dealt round-robin to the ranks, ONE launch per rank
+             (zdr_render_params.tile_shard_*); union is bit-identical to the unsharded image.  BASELINE configs[3].
+  "rows"     pixel tiles: interleaved bands of rows (one launch per band); union bit-identical as well
   "samples"  sample-index ranges [k*spp/N, (k+1)*spp/N) of the same sample set
   "seeds"    every rank renders the whole image with its own seed (seed + rank * SEED_STRIDE); the
              mean over ranks is an N*spp-sample estimate (weak scaling: fixed work per GPU)
@@ -32,10 +34,13 @@ class Shard:
     samples: Tuple[int, int]                      # sample-index range
     seed: int
     scale: float                                  # factor applied after the sum over ranks
+    tile_shard: Optional[Tuple[int, int]] = None  # (index, count): interleaved 8x8 tiles of every rectangle
 
 
 def plan(mode: str, rank: int, world: int, res, spp: int, seed: int) -> Shard:
     W, H = int(res[0]), int(res[1])
+    if mode == "tiles":
+        return Shard([(0, 0, W, H)], (0, spp), seed, 1.0, (rank, world) if world > 1 else None)
     if mode == "rows":
         rects = [(0, y, W, min(y + BAND_ROWS, H)) for i, y in enumerate(range(0, H, BAND_ROWS)) if i % world == rank]
         return Shard(rects, (0, spp), seed, 1.0)
@@ -48,10 +53,10 @@ def plan(mode: str, rank: int, world: int, res, spp: int, seed: int) -> Shard:
 
 
 class ShardedRenderer:
-    """local_forward(material, res, spp, seed, rect, samples, out) -> image (writes the shard into out)
-    local_backward(grad_output, d_material, material, res, spp, seed, rect, samples) accumulates."""
+    """local_forward(material, res, spp, seed, rect, samples, out, tile_shard) -> image (writes the shard into out)
+    local_backward(grad_output, d_material, material, res, spp, seed, rect, samples, tile_shard) accumulates."""
 
-    def __init__(self, local_forward: Callable, local_backward: Callable, mode: str = "rows", group=None):
+    def __init__(self, local_forward: Callable, local_backward: Callable, mode: str = "tiles", group=None):
         self.local_forward, self.local_backward, self.mode, self.group = local_forward, local_backward, mode, group
 
     @property
@@ -73,7 +78,7 @@ class ShardedRenderer:
         sh = plan(self.mode, self.rank, self.world, res, spp, seed)
         image = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=material.device)
         for rect in sh.rects:
-            self.local_forward(material, res, spp, sh.seed, rect, sh.samples, image)
+            self.local_forward(material, res, spp, sh.seed, rect, sh.samples, image, sh.tile_shard)
         return self._reduce(image, sh.scale)
 
     def backward(self, grad_output, material, res, spp, seed):
@@ -81,7 +86,7 @@ class ShardedRenderer:
         sh = plan(self.mode, self.rank, self.world, res, spp, seed)
         d_material = torch.zeros_like(material)
         for rect in sh.rects:
-            self.local_backward(grad_output, d_material, material, res, spp, sh.seed, rect, sh.samples)
+            self.local_backward(grad_output, d_material, material, res, spp, sh.seed, rect, sh.samples, sh.tile_shard)
         return self._reduce(d_material, sh.scale)
 
     def render(self, material, *, res, spp, seed=0):
@@ -102,13 +107,13 @@ class _ShardedOp(torch.autograd.Function):
         return ctx.renderer.backward(grad_output.contiguous(), material.detach(), res, spp, seed), None, None, None, None
 
 
-def attach(scene, mode: str = "rows", group=None) -> ShardedRenderer:
+def attach(scene, mode: str = "tiles", group=None) -> ShardedRenderer:
     """Shard the renders of a zdr_amd.Scene over the ranks of ``group``."""
-    def fwd(material, res, spp, seed, rect, samples, out):
-        return scene.render_forward(material, res, spp, seed, rect=rect, samples=samples, out=out)
+    def fwd(material, res, spp, seed, rect, samples, out, tile_shard=None):
+        return scene.render_forward(material, res, spp, seed, rect=rect, samples=samples, out=out, tile_shard=tile_shard)
 
-    def bwd(grad_output, d_material, material, res, spp, seed, rect, samples):
-        return scene.render_backward(grad_output, d_material, material, res, spp, seed, rect=rect, samples=samples)
+    def bwd(grad_output, d_material, material, res, spp, seed, rect, samples, tile_shard=None):
+        return scene.render_backward(grad_output, d_material, material, res, spp, seed, rect=rect, samples=samples, tile_shard=tile_shard)
 
     return ShardedRenderer(fwd, bwd, mode, group)
 

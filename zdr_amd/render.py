@@ -122,7 +122,7 @@ class Scene:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _params(self, res, spp, seed, tex_hw, rect=None, samples=None, camera=None, integrator=None) -> N.RenderParams:
+    def _params(self, res, spp, seed, tex_hw, rect=None, samples=None, camera=None, integrator=None, tile_shard=None) -> N.RenderParams:
         if self.sampler == "pmj02bn" and not getattr(self, "_pmj_tables_set", False):
             # the reference's pbrt tables are not shipped: fall back to generated ones (zdr_amd/pmj02bn_tables.py)
             from . import pmj02bn_tables
@@ -137,6 +137,7 @@ class Scene:
         p.max_depth, p.rr_depth = int(self.max_depth), int(self.rr_depth)
         p.camera = _camera_pod(camera if camera is not None else self.camera)
         p.tex_h, p.tex_w = int(tex_hw[0]), int(tex_hw[1])
+        p.tile_shard_index, p.tile_shard_count = tile_shard if tile_shard is not None else (0, 1)
         return p
 
     def _check_material(self, material):
@@ -144,34 +145,35 @@ class Scene:
         if material.device != self.device or material.dtype != torch.float32:
             raise ValueError(f"material must be a float32 tensor on {self.device}")
 
-    def render_forward(self, material, res, spp, seed, *, rect=None, samples=None, out=None, kernel=None):
-        """render.py:159-173.  Returns the (H, W, 4) image; with ``rect``/``samples`` only that shard
-        is written (other pixels of ``out`` keep their value; a fresh image is zero-filled)."""
+    def render_forward(self, material, res, spp, seed, *, rect=None, samples=None, out=None, kernel=None, tile_shard=None):
+        """render.py:159-173.  Returns the (H, W, 4) image; with ``rect``/``samples``/``tile_shard`` only that shard
+        is written (other pixels of ``out`` keep their value; a fresh image is zero-filled).  ``tile_shard`` =
+        (index, count): the 8x8 tiles of the rectangle numbered index, index + count, ... (include/zdr.h)."""
         self._check_material(material)
         material = material.detach().contiguous()
         if out is None:   # zero-filled even when the call covers every pixel: a dropped work item must never surface as uninitialised memory
             image = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=self.device)
         else:
             image = out
-        p = self._params(res, spp, seed, material.shape[0:2], rect, samples, integrator=kernel)
+        p = self._params(res, spp, seed, material.shape[0:2], rect, samples, integrator=kernel, tile_shard=tile_shard)
         N.check(N.lib().zdr_render_forward(self._handle, C.byref(p), material.data_ptr(), image.data_ptr(), self._stream()))
         return image
 
-    def render_backward(self, grad_output, d_material, material, res, spp, seed, *, rect=None, samples=None, camera=None):
+    def render_backward(self, grad_output, d_material, material, res, spp, seed, *, rect=None, samples=None, camera=None, tile_shard=None):
         """render.py:176-199: accumulates into ``d_material``; uses ``seed + 1`` like the reference (:196)."""
         self._check_material(material)
         material = material.detach().contiguous()
         g = grad_output.reshape(res[1], res[0], 4).contiguous()
         assert d_material.is_contiguous() and d_material.shape == material.shape
-        p = self._params(res, spp, seed + 1, material.shape[0:2], rect, samples, camera)
+        p = self._params(res, spp, seed + 1, material.shape[0:2], rect, samples, camera, tile_shard=tile_shard)
         N.check(N.lib().zdr_render_backward(self._handle, C.byref(p), g.data_ptr(), material.data_ptr(), d_material.data_ptr(), self._stream()))
         return d_material, None, None, None, None
 
-    def render_stats(self, material, res, spp, seed=0, *, rect=None, samples=None) -> dict:
+    def render_stats(self, material, res, spp, seed=0, *, rect=None, samples=None, tile_shard=None) -> dict:
         """Path statistics of one forward pass (camera samples, rays, shaded vertices ...), SURVEY §8d."""
         self._check_material(material)
         material = material.detach().contiguous()
-        p = self._params(res, spp, seed, material.shape[0:2], rect, samples)
+        p = self._params(res, spp, seed, material.shape[0:2], rect, samples, tile_shard=tile_shard)
         cnt = (C.c_uint64 * 8)()
         N.check(N.lib().zdr_render_stats(self._handle, C.byref(p), material.data_ptr(), cnt, self._stream()))
         return dict(zip(N.COUNTER_NAMES, list(cnt)))

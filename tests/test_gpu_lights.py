@@ -84,11 +84,11 @@ def test_update_lights_against_the_oracle(integrator, stage):
         if n == 0:
             assert img[..., :3].max() == 0.0 and ref[..., :3].max() == 0.0
             continue
-        assert_image_parity(img[..., :3], ref[..., :3], f"update_lights step {k} {integrator} forward")
+        assert_image_parity(img[..., :3], ref[..., :3], f"update_lights step {k} {integrator} forward", n_paths=W * W * spp)
         g = torch.zeros_like(m)
         scene.render_backward(torch.from_numpy(ones).cuda(), g, m, (W, W), spp, 20 + k)
         gref = S.render_backward(oracle_params(scene, W, W, spp, 21 + k, mat.shape[:2]), ones, mat)
-        assert_grad_parity(g.cpu().numpy(), gref, f"update_lights step {k} {integrator} backward")
+        assert_grad_parity(g.cpu().numpy(), gref, f"update_lights step {k} {integrator} backward", n_paths=W * W * spp)
     S.set_emissions(A.inst_emission)
 
 
@@ -106,6 +106,6 @@ def test_backward_replays_the_emission_snapshot_of_its_forward(stage):
     e = np.zeros((5, 3), np.float32); e[1] = 20.0; e[2] = (6.0, 2.0, 1.0)
     S.set_emissions(e)
     gref = S.render_backward(oracle_params(scene, 48, 48, 16, 3, mat.shape[:2]), np.ones((48, 48, 4), np.float32), mat)
-    assert_grad_parity(m.grad.cpu().numpy(), gref, "backward under the forward's emission snapshot")
+    assert_grad_parity(m.grad.cpu().numpy(), gref, "backward under the forward's emission snapshot", n_paths=48 * 48 * 16)
     assert scene.emissions is first
     S.set_emissions(A.inst_emission)

@@ -147,6 +147,19 @@ int zdr_trace_any(zdr_scene *scene, const float *rays, uint32_t n, int32_t *occl
 int zdr_sampler_dump(zdr_scene *scene, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries,
                      uint32_t n, int32_t nvert, int32_t rr_depth, float *out, void *stream);
 
+/* Per-path traces of the path integrator, for comparing the kernels with the oracle PATH BY PATH (glossy materials
+ * amplify last-ulp differences, so whole-image statistics alone cannot tell a flipped branch from wrong arithmetic).
+ * For each of n queries {px, py, sample_index} (DEVICE int32 n x 3) the camera sample is walked with the device
+ * functions of the path kernels (prb.py:19-88) and swept like the backward kernel (prb.py:92-187); `params` as for
+ * zdr_render_backward (its seed is used as it is), d_image the cotangent (DEVICE, or NULL = ones).
+ * out (DEVICE float32, n x (8 + 24 maxv), 1 <= maxv <= 16):
+ *   header  {bits(nvert), L.rgb — the sample's radiance before the clamp of integrator.py:26 —, 0, Li.rgb of the emitter that ended it}
+ *   vertex  {bits(inst), bits(prim), uv.xy, bits(flags), pdf_bsdf, wi.xyz (world), beta.rgb leaving the vertex,
+ *            grad.rgba (what the backward pass scatters at uv for this vertex), NEE radiance.rgb, 0 x 5}
+ *   flags = light sample accepted | path went on << 1 | Russian roulette kind << 2 (0 none, 1 stochastic, 2 renormalising). */
+int zdr_path_dump(zdr_scene *scene, const zdr_render_params *params, const float *material, const float *d_image,
+                  const int32_t *queries, uint32_t n, int32_t maxv, float *out, void *stream);
+
 /* Host-only: builds the acceleration structure exactly as zdr_scene_create does and returns it,
  * without touching a GPU, so that the CPU test-suite can run an emulation of the device traversal
  * on the very data the kernels read (tests/test_bvh_emulation.py).  tri_xyz: ntris x 9 world-space

@@ -63,6 +63,7 @@ def lib(variant: str = "ieee"):
         L.zdro_scene_set_envmap.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, fp, ip, C.c_int, fp, C.c_int, C.c_int]
         L.zdro_render_forward.argtypes = [C.c_void_p, C.POINTER(Params), fp, fp, C.POINTER(C.c_uint64)]
         L.zdro_render_backward.argtypes = [C.c_void_p, C.POINTER(Params), fp, fp, fp, C.POINTER(C.c_uint64)]
+        L.zdro_path_dump.argtypes = [C.c_void_p, C.POINTER(Params), fp, fp, ip, C.c_int, C.c_int, fp]
         L.zdro_trace_closest.argtypes = [C.c_void_p, fp, C.c_int, ip, fp]
         L.zdro_trace_any.argtypes = [C.c_void_p, fp, C.c_int, ip]
         L.zdro_xxhash32_4.restype = C.c_uint32
@@ -166,6 +167,17 @@ class OracleScene:
         if rc:
             raise RuntimeError(f"oracle backward failed rc={rc}")
         return (dm, dict(zip(COUNTER_NAMES, list(cnt)))) if counters else dm
+
+    def path_dump(self, params: Params, material: np.ndarray, queries: np.ndarray, d_image=None, maxv: int = 16) -> np.ndarray:
+        """queries (n, 3) int32 {px, py, sample_index} -> (n, 8 + 24 maxv) float32 per-path trace (layout: zdr_oracle.c)."""
+        material = np.ascontiguousarray(material, np.float32)
+        q = np.ascontiguousarray(queries, np.int32).reshape(-1, 3)
+        out = np.zeros((q.shape[0], 8 + 24 * maxv), np.float32)
+        cot = None if d_image is None else np.ascontiguousarray(d_image, np.float32)
+        rc = self._L.zdro_path_dump(self.h, C.byref(params), _f(material), None if cot is None else _f(cot), _i(q), q.shape[0], maxv, _f(out))
+        if rc:
+            raise RuntimeError(f"oracle path_dump failed rc={rc}")
+        return out
 
     def trace_closest(self, rays: np.ndarray):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

@@ -933,6 +933,7 @@ typedef struct {
     int rr_scaled, rr_norm;        /* RR divided beta by q = lum(beta') (>= 0.05); ... and lum(beta') >= 1 */
     float nee_pb_frac;             /* pdf_bsdf / (pdf_light + pdf_bsdf) of the accepted light sample */
     v3 beta_out;                   /* throughput leaving the vertex (unit luminance when rr_scaled) */
+    int inst, prim; v3 wi_world, L_nee;   /* zdro_path_dump only: the hit, the sampled direction in world space, the NEE radiance added here */
 } path_vertex_t;
 
 /* prb.py:19-88 with the current helper signatures (App. B-1). Optionally records
@@ -978,7 +979,7 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
         v3 diffuse = V3(m.x, m.y, m.z); float roughness = m.w; const float specular = 0.04f;
         C->c[C_SHADED]++;
         path_vertex_t *pv = rec ? &rec[nr] : 0;
-        if (pv) { memset(pv, 0, sizeof *pv); pv->uv = it.uv; pv->mat = m; pv->beta = beta; pv->q = 1.0f; }
+        if (pv) { memset(pv, 0, sizeof *pv); pv->uv = it.uv; pv->mat = m; pv->beta = beta; pv->q = 1.0f; pv->inst = hit.inst; pv->prim = hit.prim; }
         nr++;
         onb_t onb = make_onb(it.ns);
         v3 wo = to_local(&onb, vneg(ray.d));
@@ -994,7 +995,8 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
             float mis = balanced_heuristic(light.pdf, pb);
             float dn = fmaxf(light.pdf, 1e-4f);
             radiance = vadd(radiance, vdivs(vmul(vscale(vmul(beta, bsdf), mis), light.eval), dn));
-            if (pv) { pv->has_nee = 1; pv->wi_light = wil; pv->W = vdivs(vscale(light.eval, mis), dn);
+            if (pv) { pv->L_nee = vdivs(vmul(vscale(vmul(beta, bsdf), mis), light.eval), dn);
+                      pv->has_nee = 1; pv->wi_light = wil; pv->W = vdivs(vscale(light.eval, mis), dn);
                       pv->nee_pb_frac = (light.pdf + pb > 1e-4f) ? pb / (light.pdf + pb) : 0.0f; }
         }
         v3 wi_local = ggx_sample(wo, roughness, smp);
@@ -1014,7 +1016,7 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
             beta = vdivs(beta, q);
             if (pv && l >= 0.05f && !(g_debug_rr_clamp && l >= 1.0f)) { pv->rr_scaled = 1; pv->rr_norm = l >= 1.0f; }
         }
-        if (pv) { pv->has_bsdf = 1; pv->wi = wi_local; pv->pdf = pdf_bsdf; pv->q = q; pv->beta_out = beta; }
+        if (pv) { pv->has_bsdf = 1; pv->wi = wi_local; pv->wi_world = wi; pv->pdf = pdf_bsdf; pv->q = q; pv->beta_out = beta; }
     }
     if (nrec) *nrec = nr;
     return radiance;
@@ -1023,11 +1025,14 @@ static v3 path_walk(const zdro_scene *s, const zdro_params *P, const float *mat,
 /* PRB adjoint (prb.py:92-187). One forward walk records the shaded vertices; the
  * sweep runs last-to-first carrying Li. ZDRO_PRB_LITERAL
  * reproduces the weight of prb.py:162 (beta/pdf * Le_remaining) for comparison. */
+typedef struct { path_vertex_t rec[ZDRO_MAX_DEPTH]; v4 grad[ZDRO_MAX_DEPTH]; int n; v3 L, term_Li; } path_trace_t;   /* zdro_path_dump */
 static void path_backward(const zdro_scene *s, const zdro_params *P, const float *mat, double *dmat, ray_t ray,
-                          sampler_t *smp, v3 le_grad, counters_t *C) {
-    path_vertex_t rec[ZDRO_MAX_DEPTH];
+                          sampler_t *smp, v3 le_grad, counters_t *C, path_trace_t *trace) {
+    path_vertex_t rec_local[ZDRO_MAX_DEPTH];
+    path_vertex_t *rec = trace ? trace->rec : rec_local;
     int n = 0; v3 Li; float term_pl_frac = 0.0f;
     v3 Le = path_walk(s, P, mat, ray, smp, rec, &n, &Li, C, &term_pl_frac);
+    if (trace) { trace->n = n; trace->L = Le; trace->term_Li = Li; memset(trace->grad, 0, sizeof trace->grad); }
     if (vany_nan(Le)) return; /* prb.py:100 */
     const float specular = 0.04f;
     /* Adjoint sweep, last vertex to first, extended to the derivative of the forward's
@@ -1105,7 +1110,8 @@ static void path_backward(const zdro_scene *s, const zdro_params *P, const float
         }
         Lg = vadd(vmul(vmul(fL, v->W), le_grad), vmul(T, Y));
         Li = vadd(vmul(fL, v->W), vmul(T, Li));
-        if (v4_any_nonzero(grad) && !v4_any_nan(grad)) { /* prb.py:178-187 */
+        if (trace) trace->grad[k] = grad;
+        if (dmat && v4_any_nonzero(grad) && !v4_any_nan(grad)) { /* prb.py:178-187 */
             write_bsdf_grad(dmat, P->tex_h, P->tex_w, v->uv, grad); C->c[C_SCATTER]++;
         }
     }
@@ -1221,7 +1227,7 @@ int zdro_render_backward(const zdro_scene *s, const zdro_params *P, const float 
                     C.c[C_SAMPLES]++;
                     if (P->integrator == ZDRO_COLLOCATED) collocated_backward(s, P, material, dm, ray, le_grad, &C);
                     else if (P->integrator == ZDRO_DIRECT) (void)direct_walk(s, P, material, ray, &smp, dm, le_grad, &C);
-                    else path_backward(s, P, material, dm, ray, &smp, le_grad, &C);
+                    else path_backward(s, P, material, dm, ray, &smp, le_grad, &C, 0);
                 }
             }
 #pragma omp critical
@@ -1231,6 +1237,50 @@ int zdro_render_backward(const zdro_scene *s, const zdro_params *P, const float 
     for (size_t i = 0; i < ntex; i++) d_material[i] = (float)((double)d_material[i] + dm[i]);
     free(dm);
     if (counters) memcpy(counters, total.c, sizeof total.c);
+    return 0;
+}
+
+/* Per-path trace of the path integrator (test hook; twin of zdr_path_dump in include/zdr.h, same layout):
+ * for each query {px, py, sample_index} the path of that camera sample as path_backward walks it.
+ * out: n x (8 + 24 maxv) floats
+ *   header  {bits(nvert), L.rgb (unclamped radiance of the sample), 0, term_Li.rgb}
+ *   vertex  {bits(inst), bits(prim), uv.xy, bits(flags), pdf_bsdf, wi.xyz (world), beta_out.rgb, grad.rgba,
+ *            L_nee.rgb, 0 x 5};  flags = has_nee | has_bsdf << 1 | rr_kind << 2 (rr_kind 0 none, 1 stochastic, 2 renormalising)
+ * d_image NULL = a cotangent of ones.  The gradient is what the backward pass scatters for this vertex. */
+int zdro_path_dump(const zdro_scene *s, const zdro_params *P, const float *material, const float *d_image,
+                   const int32_t *queries, int n, int maxv, float *out) {
+    int rc = check_params(P); if (rc) return rc;
+    if (maxv < 1 || maxv > ZDRO_MAX_DEPTH) return -4;
+    const int stride = 8 + 24 * maxv;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < n; i++) {
+        const int x = queries[3 * i], y = queries[3 * i + 1]; const uint32_t it = (uint32_t)queries[3 * i + 2];
+        float *o = out + (size_t)i * stride;
+        memset(o, 0, sizeof(float) * stride);
+        v3 le_grad = V3(1.0f / (float)P->spp, 1.0f / (float)P->spp, 1.0f / (float)P->spp);
+        if (d_image) {
+            const float *g = d_image + 4 * ((size_t)x + (size_t)y * P->width);
+            le_grad = V3(g[0] / (float)P->spp, g[1] / (float)P->spp, g[2] / (float)P->spp);
+            if (vany_nan(le_grad)) le_grad = V3(0, 0, 0);
+        }
+        sampler_t smp = make_sampler(P->sampler, x, y, P->seed, P->spp, it);
+        ray_t ray = pixel_ray(P, x, y, &smp);
+        counters_t C; memset(&C, 0, sizeof C);
+        path_trace_t T; memset(&T, 0, sizeof T);
+        path_backward(s, P, material, 0, ray, &smp, le_grad, &C, &T);
+        int32_t nv = T.n; memcpy(&o[0], &nv, 4);
+        o[1] = T.L.x; o[2] = T.L.y; o[3] = T.L.z; o[5] = T.term_Li.x; o[6] = T.term_Li.y; o[7] = T.term_Li.z;
+        for (int k = 0; k < T.n && k < maxv; k++) {
+            const path_vertex_t *v = &T.rec[k];
+            float *q = o + 8 + 24 * k;
+            int32_t fl = (v->has_nee ? 1 : 0) | (v->has_bsdf ? 2 : 0) | ((v->rr_scaled ? (v->rr_norm ? 2 : 1) : 0) << 2);
+            memcpy(&q[0], &v->inst, 4); memcpy(&q[1], &v->prim, 4); q[2] = v->uv.x; q[3] = v->uv.y; memcpy(&q[4], &fl, 4);
+            if (v->has_bsdf) { q[5] = v->pdf; q[6] = v->wi_world.x; q[7] = v->wi_world.y; q[8] = v->wi_world.z;
+                               q[9] = v->beta_out.x; q[10] = v->beta_out.y; q[11] = v->beta_out.z; }
+            q[12] = T.grad[k].x; q[13] = T.grad[k].y; q[14] = T.grad[k].z; q[15] = T.grad[k].w;
+            q[16] = v->L_nee.x; q[17] = v->L_nee.y; q[18] = v->L_nee.z;
+        }
+    }
     return 0;
 }
 

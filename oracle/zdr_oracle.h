@@ -73,6 +73,10 @@ int zdro_render_forward(const zdro_scene *, const zdro_params *, const float *ma
 int zdro_render_backward(const zdro_scene *, const zdro_params *, const float *d_image,
                          const float *material, float *d_material, uint64_t *counters);
 
+/* Per-path trace of the path integrator (twin of zdr_path_dump, include/zdr.h; layout in zdr_oracle.c). */
+int zdro_path_dump(const zdro_scene *, const zdro_params *, const float *material, const float *d_image /* or NULL */,
+                   const int32_t *queries /* n x 3 */, int n, int maxv, float *out /* n x (8 + 24 maxv) */);
+
 /* Batch ray queries (LuisaCompute Accel.trace_closest / trace_any).
  * rays: n x 8 {o[3], tmin, d[3], tmax}; hits: n x 4 {inst, prim, as-float u, v}, t in tout. */
 void zdro_trace_closest(const zdro_scene *, const float *rays, int n, int32_t *inst_prim /* n x 2 */,

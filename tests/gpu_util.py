@@ -32,8 +32,9 @@ def image_diff_stats(got, ref):
 
 
 # a whole-tensor sum is dominated by a few flipped paths (heavy tail): give it more head-room than the
-# robust per-element statistics
-FLOOR_FACTORS = {"frac_bad": 2.0, "mean_rel": 2.0, "rel_l1": 2.0, "sum_rel": 6.0}
+# robust per-element statistics.  Measured HIP / floor ratios of the robust statistics on renders of >= 64^2 pixels:
+# 0.9 - 1.2 (round 2); tests/test_gpu_paths.py makes the same comparison path by path.
+FLOOR_FACTORS = {"frac_bad": 1.5, "mean_rel": 1.5, "rel_l1": 1.5, "sum_rel": 6.0}
 
 
 MAX_FLIPPED_PATHS = 20

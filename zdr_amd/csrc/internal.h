@@ -54,3 +54,5 @@ int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *ra
                      int32_t *out_i, float *out_f, hipStream_t stream);
 int zdr_launch_sampler_dump(const SamplerCfg &C, const int32_t *queries, uint32_t n, int32_t nvert,
                             int32_t rr_depth, float *out, hipStream_t stream);
+int zdr_launch_path_dump(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int accel_is_bvh,
+                         const int32_t *queries, uint32_t n, int32_t maxv, float *out, hipStream_t stream);

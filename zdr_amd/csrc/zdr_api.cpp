@@ -779,6 +779,21 @@ extern "C" int zdr_trace_any(zdr_scene *s, const float *rays, uint32_t n, int32_
     return ZDR_OK;
 }
 
+extern "C" int zdr_path_dump(zdr_scene *s, const zdr_render_params *p, const float *material, const float *d_image,
+                             const int32_t *queries, uint32_t n, int32_t maxv, float *out, void *stream) {
+    if (!s || !p || !material || !queries || !out) return fail(ZDR_E_INVALID, "null argument");
+    if (p->integrator != ZDR_PATH) return fail(ZDR_E_UNSUPPORTED, "path traces exist for the path integrator only");
+    if (maxv < 1 || maxv > ZDR_MAX_RECORDED_DEPTH) return fail(ZDR_E_INVALID, "maxv must lie in [1, 16]");
+    HIPCHK(hipSetDevice(s->device));
+    RenderCfg R; SamplerCfg C;
+    int rc = make_render_cfg(p, true, R); if (rc) return rc;
+    rc = make_sampler_cfg(s, p->sampler, p->seed, p->spp, C); if (rc) return rc;
+    KernelIO io; memset(&io, 0, sizeof io);
+    io.material = (const float4 *)material; io.d_image = (const float4 *)d_image;
+    if (zdr_launch_path_dump(s->ds, R, C, io, s->accel_is_bvh, queries, n, maxv, out, (hipStream_t)stream)) return fail(ZDR_E_HIP, "path dump launch failed");
+    return ZDR_OK;
+}
+
 extern "C" int zdr_sampler_dump(zdr_scene *s, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries, uint32_t n,
                                 int32_t nvert, int32_t rr_depth, float *out, void *stream) {
     if (!s || !queries || !out || nvert < 0) return fail(ZDR_E_INVALID, "bad argument");

@@ -632,6 +632,81 @@ int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *ra
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ------------------------------------------------------------------------------- path dump
+// Test hook (zdr_path_dump, include/zdr.h): lane = one queried camera sample, walked vertex by vertex with the SAME
+// device functions the path kernels run (path_arrive, path_shade, path_continue, pack_vertex, sweep_vertex), records kept
+// per lane.  What it writes per path is what k_path adds to the pixel and what k_path_bwd queues for the scatter.
+template <int SK, class A, bool ENV>
+__global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, SamplerCfg C, KernelIO io, const int32_t *queries, uint32_t n, int maxv, float *out) {
+    extern __shared__ int lds[];
+    const uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;                                     // no wave-level operation below: lanes are independent
+    const int stride = 8 + 24 * maxv;
+    float *o = out + (size_t)i * stride;
+    for (int k = 0; k < stride; k++) o[k] = 0.0f;
+    const int px = queries[3 * i], py = queries[3 * i + 1];
+    const uint32_t idx = (uint32_t)queries[3 * i + 2];
+    Counters cnt;
+    const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)px, (uint32_t)py, C.seed, 0u) : 0u;
+    PathState ps;
+    ps.smp = sampler_make<SK>(C, (uint32_t)px, (uint32_t)py, perm_seed, idx);
+    pixel_ray<SK>(R, C, ps.smp, px, py, ps.o, ps.d);
+    ps.beta = mk3(1.0f); ps.L = mk3(0.0f); ps.pdf_bsdf = 1e30f; ps.depth = 0;
+    f3 le_grad = mk3(R.inv_spp);
+    if (io.d_image) {                                       // integrator.py:38-40
+        const float4 gi = io.d_image[(size_t)px + (size_t)py * R.width];
+        const float fs = (float)C.spp;
+        le_grad = mk3(__fdiv_rn(gi.x, fs), __fdiv_rn(gi.y, fs), __fdiv_rn(gi.z, fs));
+        if (any_nan(le_grad)) le_grad = mk3(0.0f);
+    }
+    PackedVertex recs[ZDR_MAX_RECORDED_DEPTH];
+    Hit h = A::closest(S, lds, ps.o, ps.d, 0.0f, 1e30f);
+    Interaction it; f3 term_Li = mk3(0.0f); float plfrac = 0.0f;
+    bool done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &plfrac);
+    int nv = 0;
+    while (!done && nv < ZDR_MAX_RECORDED_DEPTH) {
+        PathVertex pv; Hit h2; h2.slot = -1; h2.u = h2.v = h2.t = 0.0f;
+        const f3 L0 = ps.L;
+        const int slot = h.slot;
+        term_Li = mk3(0.0f); plfrac = 0.0f;
+        bool stop = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h2, cnt);
+        recs[nv] = pack_vertex(pv, le_grad);
+        if (nv < maxv) {
+            float *q = o + 8 + 24 * nv;
+            const int went_on = pv.c != 0.0f ? 1 : 0;       // the BSDF sample was kept (prb.py:73-87 passed)
+            q[0] = __int_as_float(it.inst); q[1] = S.shade[8 * (size_t)slot + 7].y; q[2] = it.uv.x; q[3] = it.uv.y;
+            q[4] = __int_as_float((pv.cL != 0.0f ? 1 : 0) | (went_on << 1) | (pv.rr << 2));
+            if (went_on) { q[5] = ps.pdf_bsdf; q[6] = ps.d.x; q[7] = ps.d.y; q[8] = ps.d.z; q[9] = ps.beta.x; q[10] = ps.beta.y; q[11] = ps.beta.z; }
+            const f3 ln = ps.L - L0;
+            q[16] = ln.x; q[17] = ln.y; q[18] = ln.z;
+        }
+        nv++;
+        if (!stop) { path_continue<A, false>(S, lds, ps, h2, cnt); h = h2; stop = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &plfrac); }
+        done = stop;
+    }
+    o[0] = __int_as_float(nv); o[1] = ps.L.x; o[2] = ps.L.y; o[3] = ps.L.z; o[5] = term_Li.x; o[6] = term_Li.y; o[7] = term_Li.z;
+    if (!any_nan(ps.L) && nv > 0) {                         // prb.py:100; the sweep of k_path_bwd
+        SweepState sw; sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f; sw.tw = plfrac * dot(ps.beta, sw.A);
+        for (int k = nv - 1; k >= 0; k--) {
+            f2 guv; const float4 g = sweep_vertex(recs[k], sw, guv);
+            if (k < maxv) { float *q = o + 8 + 24 * k; q[12] = g.x; q[13] = g.y; q[14] = g.z; q[15] = g.w; }
+        }
+    }
+}
+
+int zdr_launch_path_dump(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int accel_is_bvh,
+                         const int32_t *queries, uint32_t n, int32_t maxv, float *out, hipStream_t st) {
+    if (n == 0) return 0;
+    dim3 grid((n + WAVE - 1) / WAVE);
+    const size_t dyn = accel_is_bvh ? (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int) : 0;
+#define ZDR_DUMP(SKV, ACC, ENVV) hipLaunchKernelGGL((k_path_dump<SKV, ACC, ENVV>), grid, dim3(WAVE), dyn, st, S, R, C, io, queries, n, maxv, out)
+    const bool env = S.env_count > 0, cmj = C.kind == ZDR_SAMPLER_CMJ;
+    if (accel_is_bvh) { if (cmj) { if (env) ZDR_DUMP(0, BvhAccel, true); else ZDR_DUMP(0, BvhAccel, false); } else { if (env) ZDR_DUMP(1, BvhAccel, true); else ZDR_DUMP(1, BvhAccel, false); } }
+    else { if (cmj) { if (env) ZDR_DUMP(0, BruteAccel, true); else ZDR_DUMP(0, BruteAccel, false); } else { if (env) ZDR_DUMP(1, BruteAccel, true); else ZDR_DUMP(1, BruteAccel, false); } }
+#undef ZDR_DUMP
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---------------------------------------------------------------------------- sampler dump
 template <int SK>
 __global__ void k_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n, int nvert, int rr_depth, float *out) {

@@ -239,3 +239,15 @@ class Scene:
         out = torch.empty((q.shape[0], 2 + 8 * nvert), dtype=torch.float32, device=self.device)
         N.check(N.lib().zdr_sampler_dump(self._handle, N.SAMPLERS[self.sampler], int(seed) & 0xFFFFFFFF, int(spp), q.data_ptr(), q.shape[0], nvert, rr_depth, out.data_ptr(), self._stream()))
         return out
+
+    def path_dump(self, material, queries, res, spp, seed, *, d_image=None, maxv=16):
+        """Per-path traces (include/zdr.h, zdr_path_dump): queries (n, 3) int32 cuda {px, py, sample_index} ->
+        (n, 8 + 24 maxv) float32.  ``seed`` is used as it is (pass seed + 1 for the paths of a backward pass)."""
+        self._check_material(material)
+        material = material.detach().contiguous()
+        q = queries.to(torch.int32).contiguous()
+        out = torch.empty((q.shape[0], 8 + 24 * maxv), dtype=torch.float32, device=self.device)
+        p = self._params(res, spp, seed, material.shape[0:2])
+        g = None if d_image is None else d_image.reshape(res[1], res[0], 4).contiguous()
+        N.check(N.lib().zdr_path_dump(self._handle, C.byref(p), material.data_ptr(), None if g is None else g.data_ptr(), q.data_ptr(), q.shape[0], maxv, out.data_ptr(), self._stream()))
+        return out

@@ -16,6 +16,8 @@ ap.add_argument("--spp", type=int, default=4096)
 ap.add_argument("--seeds", type=int, default=32)
 ap.add_argument("--rr-depth", type=int, default=2)
 ap.add_argument("--max-depth", type=int, default=16)
+ap.add_argument("--eps", type=float, default=0.01)
+ap.add_argument("--only", default="", help="comma list of diffuse,roughness,all")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fd_directional.json"))
 a = ap.parse_args()
 scene = make_scene("path")
@@ -28,7 +30,8 @@ res = {}
 for name, chans in (("diffuse", slice(0, 3)), ("roughness", slice(3, 4)), ("all", slice(0, 4))):
     delta = torch.zeros_like(material)
     delta[..., chans] = torch.rand(material[..., chans].shape, device="cuda", generator=g)
-    eps = 0.01
+    eps = a.eps
+    if a.only and name not in a.only.split(','): continue
     ad, fd = [], []
     for s in range(a.seeds):
         d = torch.zeros_like(material)
@@ -42,4 +45,4 @@ for name, chans in (("diffuse", slice(0, 3)), ("roughness", slice(3, 4)), ("all"
     sig = np.hypot(ad.std(ddof=1), fd.std(ddof=1)) / np.sqrt(a.seeds) / abs(fd.mean())
     res[name] = {"AD": ad.mean(), "AD_se": ad.std(ddof=1) / np.sqrt(a.seeds), "FD": fd.mean(), "FD_se": fd.std(ddof=1) / np.sqrt(a.seeds), "rel_err": rel, "one_sigma": sig}
     print(f"{name:9s}: AD = {ad.mean():.4f} +- {res[name]['AD_se']:.4f}  FD = {fd.mean():.4f} +- {res[name]['FD_se']:.4f}  rel-err {rel:.2e} (1 sigma {sig:.2e})", flush=True)
-json.dump({"res": W, "spp": a.spp, "seeds": a.seeds, "fd_eps": 0.01, "result": res}, open(a.out, "w"), indent=1)
+json.dump({"res": W, "spp": a.spp, "seeds": a.seeds, "fd_eps": a.eps, "result": res}, open(a.out, "w"), indent=1)

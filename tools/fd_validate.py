@@ -25,11 +25,13 @@ ap.add_argument("--tail-spp", type=int, default=1 << 16)
 ap.add_argument("--tail-seeds", type=int, default=64)
 ap.add_argument("--pick-seed", type=int, default=0)
 ap.add_argument("--pick", default="sample", choices=["sample", "max"], help="texel: importance-sample |grad| (reference) or take the strongest texel of a 4096-spp gradient")
+ap.add_argument("--eps", type=float, default=0.01, help="finite-difference step (fd_validate.py:92 uses 0.01)")
+ap.add_argument("--skip-table", action="store_true", help="only the high-sample tail")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fd_validate.json"))
 a = ap.parse_args()
 
 RES = (1024, 1024)
-FD_EPS = 0.01
+FD_EPS = a.eps
 SEEDS = [0, 12345, 853402567, 19260817, 948377263]
 scene = make_scene("path")
 material = torch.from_numpy(fd_material_np(1024, 0)).cuda()
@@ -69,7 +71,7 @@ print("Texture index:", texidx, " texel value:", material[texidx].item(), " texe
 assert FD_EPS <= material[texidx].item() <= 1 - FD_EPS
 
 y, x, c = imgidx
-rect = (x // 8 * 8, y // 8 * 8, x // 8 * 8 + 8, y // 8 * 8 + 8)
+rect = (x, y, x + 1, y + 1)      # only this pixel is read: render nothing else (the C-ABI's shard rectangle)
 
 def fd_grad(spp, seed):
     vals = []
@@ -85,15 +87,20 @@ def ad_grad(spp, seed):
     return d[texidx].item()
 
 rows = {"FD": [], "AD": []}
-for name, fn in (("FD", fd_grad), ("AD", ad_grad)):
+for name, fn in (() if a.skip_table else (("FD", fd_grad), ("AD", ad_grad))):
     print(f"{name}:  (rows: spp = 2^0 .. 2^12, columns: seeds {SEEDS})")
     for e in range(13):
         r = [fn(2 ** e, s) for s in SEEDS]
         rows[name].append(r)
         print(" ".join(f"{v: .6f}" for v in r))
 t0 = time.time()
-fd = np.array([fd_grad(a.tail_spp, 1000 + s) for s in range(a.tail_seeds)])
-ad = np.array([ad_grad(a.tail_spp, 5000 + s) for s in range(a.tail_seeds)])
+fd, ad = [], []
+for s in range(a.tail_seeds):
+    fd.append(fd_grad(a.tail_spp, 1000 + s)); ad.append(ad_grad(a.tail_spp, 500000 + s))
+    if (s + 1) % 64 == 0:
+        f_, a_ = np.array(fd), np.array(ad)
+        print(f"  {s + 1} seeds ({time.time() - t0:.0f} s): FD {f_.mean():.6f} +- {f_.std(ddof=1) / np.sqrt(len(f_)):.6f}  AD {a_.mean():.6f} +- {a_.std(ddof=1) / np.sqrt(len(a_)):.6f}", flush=True)
+fd, ad = np.array(fd), np.array(ad)
 fd_m, ad_m = fd.mean(), ad.mean()
 fd_se, ad_se = fd.std(ddof=1) / np.sqrt(len(fd)), ad.std(ddof=1) / np.sqrt(len(ad))
 rel = abs(ad_m - fd_m) / abs(fd_m)

@@ -28,6 +28,12 @@
 #ifndef ZDR_LDS_VERTICES_BVH
 #define ZDR_LDS_VERTICES_BVH 1
 #endif
+#ifndef ZDR_BVH_RAY_POOL
+#define ZDR_BVH_RAY_POOL 1        // BvhAccel::shadow_and_closest: continuation rays of the wave pooled in LDS, lanes take them as they become free
+#endif
+#ifndef ZDR_BVH_UNIFIED_FETCH
+#define ZDR_BVH_UNIFIED_FETCH 1   // BvhAccel::walk: node and leaf loads issued from one per-lane pointer before either branch runs
+#endif
 
 
 
@@ -178,7 +184,115 @@ struct BvhAccel {
     // 4-wide BVH, one 64-byte quantised node per visit (4 dwordx4 loads), nearest hit child first.
     // stack: this wave's LDS region, min(S.stack_entries, ZDR_BVH_LDS_STACK) x 64 ints; entry e of lane l at stack[e * 64 + l].
     // A work item is (id, cnt): cnt == 0 -> node id, 1..4 -> leaf slots [id, id + cnt); 7 marks an unused child and is never pushed.
-    //
+    struct Walker {                  // one ray in flight on this lane
+        f3 o, d, inv; float tmin; Hit h;
+        int sp, id, cnt, budget;
+    };
+    ZD static int root_count(const DScene &S) { return (S.nnodes == 0) ? S.ntris : 0; }
+    // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it impossible for a wave to
+    // spin forever whatever the node data or the ray (NaNs) look like.
+    ZD static int walk_budget(const DScene &S) { return (S.debug_bvh_budget > 0) ? S.debug_bvh_budget : 2 * (S.nnodes + S.ntris) + 8; }
+    ZD static void start(const DScene &S, Walker &w, f3 o, f3 d, float tmin, float tmax) {
+        w.o = o; w.d = d; w.tmin = tmin; w.inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
+        w.h.slot = -1; w.h.u = 0.0f; w.h.v = 0.0f; w.h.t = tmax;
+        w.sp = 0; w.id = 0; w.cnt = root_count(S); w.budget = walk_budget(S);
+    }
+    // One visit (a node or a leaf) and the pop that follows it.  Returns true while the ray has more to visit.
+    // Entries [0, LN) of the stack live in LDS, deeper ones in per-lane scratch (`deep`): the builder's bound (up to 44
+    // entries on a 1 M triangle tree, 11 KiB of LDS per wave) is a worst case that real rays almost never approach,
+    // and LDS is what limits the waves per CU of the BVH kernels.
+    ZD static bool step(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const bool anyhit) {
+        const int lane = threadIdx.x & 63;
+        bool ray_done = (--w.budget < 0);
+        const f3 o = w.o, d = w.d, inv = w.inv; const float tmin = w.tmin;
+        const int id = w.id, cnt = w.cnt;
+#if ZDR_BVH_UNIFIED_FETCH
+        // ONE memory round trip per trip of the wave.  The walk is latency-bound (waves sit in s_waitcnt 2/3 of the
+        // time): what counts is how many dependent round trips a wave makes, and a wave whose lanes are partly at nodes
+        // and partly at leaves used to make one for the node branch, then one per triangle of the leaf branch.  Here every
+        // lane first issues the loads of whatever it stands on — a node (64 B) or the <= 2 triangles of a leaf (48 B
+        // each) sit behind ONE per-lane pointer, four dwordx4 loads for everybody, two more for a second triangle — and
+        // only then do the branches consume them.
+        const bool at_node = !ray_done && cnt == 0, at_leaf = !ray_done && cnt != 0;
+        const float4 *p = at_node ? S.nodes + 4 * (size_t)id : S.isect + 3 * (size_t)id;   // isect is padded by one record
+        float4 n0, n1, n2, n3, n4, n5;
+        n0 = n1 = n2 = n3 = n4 = n5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!ray_done) { n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; }
+        if (at_leaf && cnt > 1) { n4 = p[4]; n5 = p[5]; }
+        if (at_node) {
+#else
+        if (!ray_done && cnt == 0) {
+            const float4 *n = S.nodes + 4 * (size_t)id;
+            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+#endif
+            // slab distances on the node's quantisation grid: t = (origin + scale q - o) / d = q A + B
+            const f3 A = mk3(n0.w * inv.x, n1.x * inv.y, n1.y * inv.z);
+            const f3 B = mk3((n0.x - o.x) * inv.x, (n0.y - o.y) * inv.y, (n0.z - o.z) * inv.z);
+            const uint32_t lxq = __float_as_uint(n1.z), lyq = __float_as_uint(n1.w), lzq = __float_as_uint(n2.x);
+            const uint32_t hxq = __float_as_uint(n2.y), hyq = __float_as_uint(n2.z), hzq = __float_as_uint(n2.w);
+            const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), c2 = __float_as_uint(n3.z), c3 = __float_as_uint(n3.w);
+            // count == 7 marks an unused child slot (a slab test cannot express "never hit")
+            float e0 = ((c0 & 7u) != 7u) ? qbox_entry<0>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, w.h.t) : 3.0e38f;
+            float e1 = ((c1 & 7u) != 7u) ? qbox_entry<1>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, w.h.t) : 3.0e38f;
+            float e2 = ((c2 & 7u) != 7u) ? qbox_entry<2>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, w.h.t) : 3.0e38f;
+            float e3 = ((c3 & 7u) != 7u) ? qbox_entry<3>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, w.h.t) : 3.0e38f;
+            int p0 = (int)c0, p1 = (int)c1, p2 = (int)c2, p3 = (int)c3;
+            // nearest child: visit now; the other hit children go on the stack.  On the fast path the four
+            // stack writes are unconditional (LDS stores are cheap, branches are not): a slot is kept only
+            // if sp advances past it.
+            float em = fminf(fminf(e0, e1), fminf(e2, e3));
+            if (em < 2.0e38f) {
+                bool t0 = (e0 == em), t1 = !t0 & (e1 == em), t2 = !(t0 | t1) & (e2 == em), t3 = !(t0 | t1 | t2);
+                int next = t0 ? p0 : (t1 ? p1 : (t2 ? p2 : p3));
+                int sp = w.sp;
+                if (sp + 4 <= LN) {
+                    int *sl = stack + sp * 64 + lane;
+                    sl[0] = p0; sl += (!t0 & (e0 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p1; sl += (!t1 & (e1 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p2; sl += (!t2 & (e2 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p3; sl += (!t3 & (e3 < 2.0e38f)) ? 64 : 0;
+                    sp = (int)((sl - (stack + lane)) >> 6);
+                } else {                                // near or past the LDS part: one entry at a time
+                    const int pp[4] = {p0, p1, p2, p3};
+                    const bool keep[4] = {!t0 && e0 < 2.0e38f, !t1 && e1 < 2.0e38f, !t2 && e2 < 2.0e38f, !t3 && e3 < 2.0e38f};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (keep[j]) {
+                            if (sp < LN) stack[sp * 64 + lane] = pp[j]; else deep[sp - LN] = pp[j];
+                            sp++;
+                        }
+                    }
+                }
+                w.sp = sp; w.id = next >> 3; w.cnt = next & 7;
+                return true;
+            }
+#if ZDR_BVH_UNIFIED_FETCH
+        } else if (at_leaf) {
+            float t;
+            if (tri_test(n0, n1, n2, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id; }
+            if (cnt > 1 && tri_test(n3, n4, n5, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id + 1; }
+            for (int s = id + 2; s < id + cnt; s++)       // leaves of more than two triangles (ZDR_BVH_LEAF > 2)
+                if (tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = s; }
+            if (anyhit && w.h.slot >= 0) ray_done = true;         // any-hit: the first hit settles it
+        }
+#else
+        } else if (!ray_done) {
+            for (int s = id; s < id + cnt; s++) {
+                float t;
+                bool ok = tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, w.h.t, t);
+                if (ok) { w.h.t = t; w.h.slot = s; }
+            }
+            if (anyhit && w.h.slot >= 0) ray_done = true;         // any-hit: the first hit settles it
+        }
+#endif
+        if (!ray_done && w.sp != 0) {
+            w.sp--;
+            int e = (w.sp < LN) ? stack[w.sp * 64 + lane] : deep[w.sp - LN];
+            w.id = e >> 3; w.cnt = e & 7;
+            return true;
+        }
+        return false;
+    }
     // One loop walks up to two rays per lane back to back: first (HAS_A) an any-hit ray — the shadow segment of a
     // path vertex — then (HAS_B, lanes with needB) a closest-hit ray — the continuation ray.  A lane starts its second
     // ray the moment its first one ends, so the wave's trip count is the longest SUM of the two walks over its
@@ -189,99 +303,74 @@ struct BvhAccel {
         occ = false;
         hit.slot = -1; hit.u = 0.0f; hit.v = 0.0f; hit.t = tmaxB;
         if (!HAS_A && !needB) return;
-        const int lane = threadIdx.x & 63;
         bool first = HAS_A;                                  // this lane is still on its any-hit ray
-        f3 o = HAS_A ? oA : oB, d = HAS_A ? dA : dB;
-        float tmin = HAS_A ? tminA : tminB;
-        Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = HAS_A ? tmaxA : tmaxB;
-        f3 inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
-        // Entries [0, LN) of the stack live in LDS, deeper ones in per-lane scratch: the builder's bound
-        // (up to 44 entries on a 1 M triangle tree, 11 KiB of LDS per wave) is a worst case that real rays
-        // almost never approach, and LDS is what limits the waves per CU of the BVH kernels.
         const int LN = (S.stack_entries < ZDR_BVH_LDS_STACK) ? S.stack_entries : ZDR_BVH_LDS_STACK;
         int deep[ZDR_BVH_STACK - ZDR_BVH_LDS_STACK + 4];
-        const int root_cnt = (S.nnodes == 0) ? S.ntris : 0;
-        int sp = 0;
-        int id = 0, cnt = root_cnt;
-        // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it
-        // impossible for a wave to spin forever whatever the node data or the ray (NaNs) look like.
-        const int budget0 = (S.debug_bvh_budget > 0) ? S.debug_bvh_budget : 2 * (S.nnodes + S.ntris) + 8;
-        int budget = budget0;
+        Walker w;
+        if (HAS_A) start(S, w, oA, dA, tminA, tmaxA); else start(S, w, oB, dB, tminB, tmaxB);
         for (;;) {
-            bool ray_done = (--budget < 0);
-            if (!ray_done && cnt == 0) {
-                const float4 *n = S.nodes + 4 * (size_t)id;
-                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-                // slab distances on the node's quantisation grid: t = (origin + scale q - o) / d = q A + B
-                const f3 A = mk3(n0.w * inv.x, n1.x * inv.y, n1.y * inv.z);
-                const f3 B = mk3((n0.x - o.x) * inv.x, (n0.y - o.y) * inv.y, (n0.z - o.z) * inv.z);
-                const uint32_t lxq = __float_as_uint(n1.z), lyq = __float_as_uint(n1.w), lzq = __float_as_uint(n2.x);
-                const uint32_t hxq = __float_as_uint(n2.y), hyq = __float_as_uint(n2.z), hzq = __float_as_uint(n2.w);
-                const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), c2 = __float_as_uint(n3.z), c3 = __float_as_uint(n3.w);
-                // count == 7 marks an unused child slot (a slab test cannot express "never hit")
-                float e0 = ((c0 & 7u) != 7u) ? qbox_entry<0>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
-                float e1 = ((c1 & 7u) != 7u) ? qbox_entry<1>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
-                float e2 = ((c2 & 7u) != 7u) ? qbox_entry<2>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
-                float e3 = ((c3 & 7u) != 7u) ? qbox_entry<3>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, h.t) : 3.0e38f;
-                int p0 = (int)c0, p1 = (int)c1, p2 = (int)c2, p3 = (int)c3;
-                // nearest child: visit now; the other hit children go on the stack.  On the fast path the four
-                // stack writes are unconditional (LDS stores are cheap, branches are not): a slot is kept only
-                // if sp advances past it.
-                float em = fminf(fminf(e0, e1), fminf(e2, e3));
-                if (em < 2.0e38f) {
-                    bool t0 = (e0 == em), t1 = !t0 & (e1 == em), t2 = !(t0 | t1) & (e2 == em), t3 = !(t0 | t1 | t2);
-                    int next = t0 ? p0 : (t1 ? p1 : (t2 ? p2 : p3));
-                    if (sp + 4 <= LN) {
-                        int *sl = stack + sp * 64 + lane;
-                        sl[0] = p0; sl += (!t0 & (e0 < 2.0e38f)) ? 64 : 0;
-                        sl[0] = p1; sl += (!t1 & (e1 < 2.0e38f)) ? 64 : 0;
-                        sl[0] = p2; sl += (!t2 & (e2 < 2.0e38f)) ? 64 : 0;
-                        sl[0] = p3; sl += (!t3 & (e3 < 2.0e38f)) ? 64 : 0;
-                        sp = (int)((sl - (stack + lane)) >> 6);
-                    } else {                                // near or past the LDS part: one entry at a time
-                        const int pp[4] = {p0, p1, p2, p3};
-                        const bool keep[4] = {!t0 && e0 < 2.0e38f, !t1 && e1 < 2.0e38f, !t2 && e2 < 2.0e38f, !t3 && e3 < 2.0e38f};
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (keep[j]) {
-                                if (sp < LN) stack[sp * 64 + lane] = pp[j]; else deep[sp - LN] = pp[j];
-                                sp++;
-                            }
-                        }
-                    }
-                    id = next >> 3; cnt = next & 7;
-                    continue;
-                }
-            } else if (!ray_done) {
-                for (int s = id; s < id + cnt; s++) {
-                    float t;
-                    bool ok = tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, h.t, t);
-                    if (ok) { h.t = t; h.slot = s; }
-                }
-                if (HAS_A && first && h.slot >= 0) ray_done = true;   // any-hit: the first hit settles it
-            }
-            if (!ray_done && sp != 0) {
-                sp--;
-                int e = (sp < LN) ? stack[sp * 64 + lane] : deep[sp - LN];
-                id = e >> 3; cnt = e & 7;
-                continue;
-            }
+            if (step(S, stack, LN, deep, w, HAS_A && first)) continue;
             // this lane's current ray has ended
+            if (w.budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);   // the walk was cut short: whatever it returns is not a result
             if (HAS_A && first) {
-                occ = h.slot >= 0;
+                occ = w.h.slot >= 0;
                 if (!HAS_B || !needB) break;
-                if (budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);
                 first = false;
-                o = oB; d = dB; tmin = tminB; inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
-                h.slot = -1; h.t = tmaxB;
-                sp = 0; id = 0; cnt = root_cnt; budget = budget0;
+                start(S, w, oB, dB, tminB, tmaxB);
                 continue;
             }
             break;
         }
-        if (budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);   // the walk was cut short: whatever it returns is not a result
-        if (HAS_B && !first && needB) { hit = h; hit_barycentrics(S, hit, oB, dB); }
+        if (HAS_B && !first && needB) { hit = w.h; hit_barycentrics(S, hit, oB, dB); }
     }
+#if ZDR_BVH_RAY_POOL
+    // Both rays of a path vertex, with the CONTINUATION rays of the whole wave in a pool (LDS, after the traversal
+    // stacks): a lane traces its own shadow ray and then takes continuation rays from the pool — whoever they belong
+    // to — until none is left, so a lane whose own rays were short (or that has no vertex at all this trip:
+    // active == false) works on instead of waiting for the wave's longest pair of walks.
+    // Called by the whole wave from a reconverged point.  Pool (ints): [0] next ray, then o.x o.y o.z d.x d.y d.z [64]
+    // each; the result (slot, t) of ray k overwrites o.x[k], o.y[k] — only the lane that traced it had read them.
+    ZD static void walk_pool(const DScene &S, int *stack, bool active, f3 oA, f3 dA, float tminA, float tmaxA,
+                             bool needB, f3 oB, f3 dB, bool &occ, Hit &hit) {
+        occ = false;
+        hit.slot = -1; hit.u = 0.0f; hit.v = 0.0f; hit.t = 1e30f;
+        const int lane = threadIdx.x & 63;
+        const int LN = (S.stack_entries < ZDR_BVH_LDS_STACK) ? S.stack_entries : ZDR_BVH_LDS_STACK;
+        int *pool = stack + LN * 64;
+        float *pf = (float *)(pool + 1);
+        const unsigned long long here = __ballot(true), mB = __ballot(needB);
+        const int nB = __popcll(mB);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+        if (needB) { pf[rank] = oB.x; pf[64 + rank] = oB.y; pf[128 + rank] = oB.z; pf[192 + rank] = dB.x; pf[256 + rank] = dB.y; pf[320 + rank] = dB.z; }
+        if (lane == __builtin_ctzll(here)) pool[0] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int deep[ZDR_BVH_STACK - ZDR_BVH_LDS_STACK + 4];
+        Walker w;
+        bool first = active;                                 // on the lane's own any-hit ray
+        bool have = active;
+        int cur = -1;                                        // pool ray in flight
+        if (active) start(S, w, oA, dA, tminA, tmaxA);
+        else { w.o = mk3(0.0f); w.d = mk3(0.0f, 0.0f, 1.0f); w.inv = mk3(0.0f); w.tmin = 0.0f; w.h.slot = -1; w.h.u = w.h.v = 0.0f; w.h.t = 0.0f; w.sp = 0; w.id = 0; w.cnt = 0; w.budget = 0; }
+        for (;;) {
+            if (!have) {
+                const int k = atomicAdd(&pool[0], 1);        // ds_add_rtn_u32
+                if (k >= nB) break;
+                cur = k; have = true;
+                start(S, w, mk3(pf[k], pf[64 + k], pf[128 + k]), mk3(pf[192 + k], pf[256 + k], pf[320 + k]), 0.0f, 1e30f);
+            }
+            if (step(S, stack, LN, deep, w, first)) continue;
+            if (w.budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);
+            if (first) { occ = w.h.slot >= 0; first = false; }
+            else { pool[1 + cur] = w.h.slot; pf[64 + cur] = w.h.t; }
+            have = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (needB) { hit.slot = pool[1 + rank]; hit.t = pf[64 + rank]; hit_barycentrics(S, hit, oB, dB); }
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         bool occ; Hit h;
         walk<false, true>(S, stack, o, d, tmin, tmax, true, o, d, tmin, tmax, occ, h);
@@ -292,7 +381,13 @@ struct BvhAccel {
         walk<true, false>(S, stack, o, d, tmin, tmax, false, o, d, tmin, tmax, occ, h);
         return occ;
     }
-    ZD static void shadow_and_closest(const DScene &S, int *stack, f3 o1, f3 d1, float tmin1, float tmax1, bool need2, f3 o2, f3 d2, bool &occ, Hit &h) {
-        walk<true, true>(S, stack, o1, d1, tmin1, tmax1, need2, o2, d2, 0.0f, 1e30f, occ, h);
+    // Called by the whole wave (path_shade); `active`: this lane has a vertex, i.e. a shadow ray (o1, d1) and — if need2 — a continuation ray
+    ZD static void shadow_and_closest(const DScene &S, int *stack, bool active, f3 o1, f3 d1, float tmin1, float tmax1, bool need2, f3 o2, f3 d2, bool &occ, Hit &h) {
+#if ZDR_BVH_RAY_POOL
+        walk_pool(S, stack, active, o1, d1, tmin1, tmax1, need2, o2, d2, occ, h);
+#else
+        occ = false; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = 1e30f;
+        if (active) walk<true, true>(S, stack, o1, d1, tmin1, tmax1, need2, o2, d2, 0.0f, 1e30f, occ, h);
+#endif
     }
 };

@@ -242,20 +242,29 @@ ZD bool path_arrive(const DScene &S, PathState &ps, const Hit &h, Interaction &i
 // BWD: fills pv, the record of this vertex.
 template <int SK, class A, bool BWD, bool STATS, bool ENV>
 ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                   PathState &ps, const Interaction &it, PathVertex &pv, Hit &h, Counters &cnt) {
-    float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
-    f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
-    COUNT(C_SHADED);
-    if (BWD) {
-        pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
-        pv.T = mk3(0.0f); pv.fLW = mk3(0.0f); pv.bnorm = mk3(0.0f); pv.neeM = mk3(0.0f); pv.dlnp = 0.0f; pv.rr = 0;
+                   PathState &ps, const Interaction &it, PathVertex &pv, Hit &h, Counters &cnt, bool active = true) {
+    // A::kFuseRays: the WHOLE wave calls this from a reconverged point and `active` says whether the lane has a vertex
+    // to shade — lanes without one still take part in the traversal (BvhAccel's ray pool: they trace other lanes'
+    // continuation rays).  Otherwise the caller only comes here with lanes that have a vertex.
+    float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    f3 diffuse = mk3(0.0f), wo = mk3(0.0f, 0.0f, 1.0f), wil = mk3(0.0f, 0.0f, 1.0f); float roughness = 1.0f;
+    Onb onb; onb.tangent = mk3(1.0f, 0.0f, 0.0f); onb.binormal = mk3(0.0f, 1.0f, 0.0f); onb.normal = mk3(0.0f, 0.0f, 1.0f);
+    LightSample light; light.wi = mk3(0.0f, 0.0f, 1.0f); light.dist = 0.0f; light.pdf = 1.0f; light.eval = mk3(0.0f);
+    if (active) {
+        m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
+        diffuse = mk3(m.x, m.y, m.z); roughness = m.w;
+        COUNT(C_SHADED);
+        if (BWD) {
+            pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
+            pv.T = mk3(0.0f); pv.fLW = mk3(0.0f); pv.bnorm = mk3(0.0f); pv.neeM = mk3(0.0f); pv.dlnp = 0.0f; pv.rr = 0;
+        }
+        onb = make_onb(it.ns);
+        wo = to_local(onb, -ps.d);
+        // next-event estimation: the light sample (prb.py:57-58)
+        float u_pick = sampler_next<SK>(C, ps.smp);
+        light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
+        wil = to_local(onb, light.wi);
     }
-    Onb onb = make_onb(it.ns);
-    f3 wo = to_local(onb, -ps.d);
-    // next-event estimation: the light sample (prb.py:57-58)
-    float u_pick = sampler_next<SK>(C, ps.smp);
-    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
-    const f3 wil = to_local(onb, light.wi);
 
     auto nee = [&](bool occluded, f3 beta_in) {                                   // prb.py:60-66; beta_in: throughput arriving at the vertex
         if (!occluded && wil.z >= 1e-4f) {
@@ -317,16 +326,19 @@ ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, con
         return stop;
     };
 
-    COUNT(C_SHADOW);
-    bool stop;
+    bool stop = true;
     if constexpr (A::kFuseRays) {
         const f3 beta_arrived = ps.beta;
-        stop = sample_bsdf();
-        if (!stop) COUNT(C_CLOSEST);
-        bool occluded;
-        A::shadow_and_closest(S, lds, it.p, light.wi, 1e-4f, light.dist, !stop, ps.o, ps.d, occluded, h);
-        nee(occluded, beta_arrived);
+        if (active) {
+            COUNT(C_SHADOW);
+            stop = sample_bsdf();
+            if (!stop) COUNT(C_CLOSEST);
+        }
+        bool occluded = false;
+        A::shadow_and_closest(S, lds, active, it.p, light.wi, 1e-4f, light.dist, active && !stop, ps.o, ps.d, occluded, h);
+        if (active) nee(occluded, beta_arrived);
     } else {
+        COUNT(C_SHADOW);
         nee(A::any(S, lds, it.p, light.wi, 1e-4f, light.dist), ps.beta);
         stop = sample_bsdf();              // the caller traces the continuation ray (path_continue), after it has put pv away
     }

@@ -402,7 +402,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     }
     s->accel_is_bvh = use_bvh ? 1 : 0;
 
-    std::vector<float4> isect(3 * (size_t)ntris), shade(8 * (size_t)ntris);
+    std::vector<float4> isect(3 * (size_t)ntris + 3, make_float4(0, 0, 0, 0)), shade(8 * (size_t)ntris);   // + one record: the BVH walk fetches four float4 behind a leaf's first triangle
     std::vector<int32_t> slot_of_tri(ntris);
     for (uint32_t slot = 0; slot < ntris; slot++) {
         const TriRec &r = rec[order[slot]];

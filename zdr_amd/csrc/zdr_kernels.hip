@@ -226,9 +226,11 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesFwd) void k_path(DScene S, Render
         if (__ballot(alive) != 0ull) {
             progress = true;
             bool done = false;
+            Hit h; h.slot = -1; h.u = h.v = h.t = 0.0f;
+            // BvhAccel traces the wave's rays together (ray pool): lanes without a vertex take part in the traversal
+            if constexpr (A::kFuseRays) done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt, alive) && alive;
             if (alive) {
-                Hit h;
-                done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
+                if constexpr (!A::kFuseRays) done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
                 if (!done) { path_continue<A, STATS>(S, lds, ps, h, cnt); done = path_arrive<false, STATS, ENV>(S, ps, h, it, term_Li, cnt); }
                 if (done) {
                     alive = false;
@@ -346,10 +348,11 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             plast.a = plast.b = plast.c = plast.d = plast.e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             int sw_k = -1;                                  // next vertex the sweep consumes
             SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
+            PathVertex pv; Hit h; h.slot = -1; h.u = h.v = h.t = 0.0f;
+            if constexpr (A::kFuseRays) done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt, alive) && alive;
             if (alive) {
-                PathVertex pv; float term_plfrac = 0.0f;
-                Hit h;
-                done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
+                float term_plfrac = 0.0f;
+                if constexpr (!A::kFuseRays) done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
                 plast = pack_vertex(pv, le_grad);
                 if (nrec < lds_vertices) plast.e = make_float4(0.0f, 0.0f, 0.0f, plast.e.w);   // LDS records carry no RR fields
                 if (!done) { path_continue<A, false>(S, lds, ps, h, cnt); done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac); }
@@ -510,6 +513,10 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 }
 
 // ----------------------------------------------------------------------------------- launch
+// dynamic LDS of a wave that traverses the BVH: the per-lane stacks and, behind them, the continuation-ray pool (accel.h)
+static size_t bvh_dyn_lds(const DScene &S) {
+    return ((size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE + (ZDR_BVH_RAY_POOL ? 1 + 6 * WAVE : 0)) * sizeof(int);
+}
 // Persistent grid of the path kernels: as many single-wave workgroups as the chip holds at once (never more
 // than there are items).  A workgroup that is not resident at first simply starts later and draws what is left.
 template <class K>
@@ -575,7 +582,7 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     int nblocks = R.ntiles * R.nchunks;
     if (nblocks <= 0) return 0;
     dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
-    const size_t dyn = accel_is_bvh ? (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int) : 0;
+    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S) : 0;
     if (io.tile_masks && !io.tile_masks_valid)
         hipLaunchKernelGGL(k_tile_masks, dim3(R.tiles_x * R.tiles_y), dim3(WAVE), 0, st, S, R, (unsigned long long *)io.tile_masks);
     if (C.kind == ZDR_SAMPLER_CMJ) {
@@ -622,7 +629,7 @@ int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *ra
     dim3 grid((n + WAVE - 1) / WAVE);
     const float4 *r = (const float4 *)rays;
     if (accel_is_bvh) {
-        const size_t dyn = (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int);
+        const size_t dyn = bvh_dyn_lds(S);
         if (any) hipLaunchKernelGGL((k_trace<BvhAccel, true>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
         else hipLaunchKernelGGL((k_trace<BvhAccel, false>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
     } else {
@@ -698,7 +705,7 @@ int zdr_launch_path_dump(const DScene &S, const RenderCfg &R, const SamplerCfg &
                          const int32_t *queries, uint32_t n, int32_t maxv, float *out, hipStream_t st) {
     if (n == 0) return 0;
     dim3 grid((n + WAVE - 1) / WAVE);
-    const size_t dyn = accel_is_bvh ? (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int) : 0;
+    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S) : 0;
 #define ZDR_DUMP(SKV, ACC, ENVV) hipLaunchKernelGGL((k_path_dump<SKV, ACC, ENVV>), grid, dim3(WAVE), dyn, st, S, R, C, io, queries, n, maxv, out)
     const bool env = S.env_count > 0, cmj = C.kind == ZDR_SAMPLER_CMJ;
     if (accel_is_bvh) { if (cmj) { if (env) ZDR_DUMP(0, BvhAccel, true); else ZDR_DUMP(0, BvhAccel, false); } else { if (env) ZDR_DUMP(1, BvhAccel, true); else ZDR_DUMP(1, BvhAccel, false); } }

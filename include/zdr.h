@@ -120,7 +120,8 @@ int zdr_render_backward(zdr_scene *scene, const zdr_render_params *params, const
 
 /* Path statistics of one forward pass over the shard: counters[8] (HOST, written
  * after an internal synchronise) = camera samples, closest-hit rays, closest rays that hit,
- * shadow rays, shaded vertices, emitter hits via BSDF sampling, NaN-dropped samples, 0. */
+ * shadow rays (one per shaded vertex, prb.py:59), shaded vertices, emitter hits via BSDF sampling, NaN-dropped samples,
+ * shadow rays actually traced (the BVH kernels skip those whose light sample carries nothing). */
 int zdr_render_stats(zdr_scene *scene, const zdr_render_params *params, const float *material,
                      uint64_t counters[8], void *stream);
 

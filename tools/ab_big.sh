@@ -7,7 +7,7 @@ for round in 1 2; do
   for v in "$@"; do
     echo "== round $round flags: [$v]"
     ZDR_KERNEL_FLAGS="$v" python -m zdr_amd.build --force > /dev/null 2>gpurun_out/ab_build.log || { tail -5 gpurun_out/ab_build.log; continue; }
-    timeout -k 10 200 python tools/run_big.py --spp $SPP --iters 3 2>&1 | grep -E "^fwd|^bwd|image mean"
+    timeout -k 10 200 python tools/run_big.py --spp $SPP --iters 3 2>&1 | grep -E "^fwd|^bwd|image mean|^stats"
     if [ "$TRACE" = "1" ] && [ $round = 1 ]; then timeout -k 10 200 python tools/trace_bench.py 2>&1 | grep -E "Mrays"; fi
   done
 done

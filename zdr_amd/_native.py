@@ -18,7 +18,7 @@ INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH}   # ren
 SAMPLERS = {"cmj": SAMPLER_CMJ, "corrmj": SAMPLER_CMJ, "pmj02bn": SAMPLER_PMJ02BN}
 ACCELS = {"auto": ACCEL_AUTO, "brute": ACCEL_BRUTE, "bvh": ACCEL_BVH}
 COUNTER_NAMES = ("samples", "closest_rays", "closest_hits", "shadow_rays", "shaded_vertices",
-                 "emitter_hits_bsdf", "nan_samples", "unused")
+                 "emitter_hits_bsdf", "nan_samples", "shadow_rays_traced")
 
 # every symbol include/zdr.h declares
 EXPORTS = ("zdr_version", "zdr_last_error", "zdr_scene_create", "zdr_scene_destroy", "zdr_scene_info",

@@ -28,13 +28,6 @@
 #ifndef ZDR_LDS_VERTICES_BVH
 #define ZDR_LDS_VERTICES_BVH 1
 #endif
-#ifndef ZDR_BVH_RAY_POOL
-#define ZDR_BVH_RAY_POOL 1        // BvhAccel::shadow_and_closest: continuation rays of the wave pooled in LDS, lanes take them as they become free
-#endif
-#ifndef ZDR_BVH_UNIFIED_FETCH
-#define ZDR_BVH_UNIFIED_FETCH 1   // BvhAccel::walk: node and leaf loads issued from one per-lane pointer before either branch runs
-#endif
-
 
 
 // The triangle array is read-only for the whole launch.  Reading it through the CONSTANT address
@@ -197,34 +190,33 @@ struct BvhAccel {
         w.h.slot = -1; w.h.u = 0.0f; w.h.v = 0.0f; w.h.t = tmax;
         w.sp = 0; w.id = 0; w.cnt = root_count(S); w.budget = walk_budget(S);
     }
-    // One visit (a node or a leaf) and the pop that follows it.  Returns true while the ray has more to visit.
+    // One visit (a node or a leaf) and the pop that follows it, in two halves: fetch() issues the loads of whatever the
+    // ray stands on, consume() uses them and returns true while the ray has more to visit.
+    // ONE memory round trip per trip of the wave.  The walk is latency-bound (waves sit in s_waitcnt 2/3 of the time):
+    // what counts is how many dependent round trips a wave makes, and a wave whose lanes are partly at nodes and partly
+    // at leaves used to make one for the node branch, then one per triangle of the leaf branch.  Here every lane first
+    // issues its loads — a node (64 B) or the <= 2 triangles of a leaf (48 B each) sit behind ONE per-lane pointer, four
+    // dwordx4 loads for everybody, two more for a second triangle — and only then do the branches consume them.
     // Entries [0, LN) of the stack live in LDS, deeper ones in per-lane scratch (`deep`): the builder's bound (up to 44
     // entries on a 1 M triangle tree, 11 KiB of LDS per wave) is a worst case that real rays almost never approach,
     // and LDS is what limits the waves per CU of the BVH kernels.
-    ZD static bool step(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const bool anyhit) {
+    struct Fetched { float4 n0, n1, n2, n3, n4, n5; bool dead; };
+    ZD static Fetched fetch(const DScene &S, Walker &w) {
+        Fetched f;
+        f.dead = (--w.budget < 0);
+        f.n0 = f.n1 = f.n2 = f.n3 = f.n4 = f.n5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 *p = (w.cnt == 0) ? S.nodes + 4 * (size_t)w.id : S.isect + 3 * (size_t)w.id;   // isect is padded by one record
+        if (!f.dead) { f.n0 = p[0]; f.n1 = p[1]; f.n2 = p[2]; f.n3 = p[3]; }
+        if (!f.dead && w.cnt > 1) { f.n4 = p[4]; f.n5 = p[5]; }
+        return f;
+    }
+    ZD static bool consume(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const Fetched &f, const bool anyhit) {
         const int lane = threadIdx.x & 63;
-        bool ray_done = (--w.budget < 0);
+        bool ray_done = f.dead;
         const f3 o = w.o, d = w.d, inv = w.inv; const float tmin = w.tmin;
         const int id = w.id, cnt = w.cnt;
-#if ZDR_BVH_UNIFIED_FETCH
-        // ONE memory round trip per trip of the wave.  The walk is latency-bound (waves sit in s_waitcnt 2/3 of the
-        // time): what counts is how many dependent round trips a wave makes, and a wave whose lanes are partly at nodes
-        // and partly at leaves used to make one for the node branch, then one per triangle of the leaf branch.  Here every
-        // lane first issues the loads of whatever it stands on — a node (64 B) or the <= 2 triangles of a leaf (48 B
-        // each) sit behind ONE per-lane pointer, four dwordx4 loads for everybody, two more for a second triangle — and
-        // only then do the branches consume them.
-        const bool at_node = !ray_done && cnt == 0, at_leaf = !ray_done && cnt != 0;
-        const float4 *p = at_node ? S.nodes + 4 * (size_t)id : S.isect + 3 * (size_t)id;   // isect is padded by one record
-        float4 n0, n1, n2, n3, n4, n5;
-        n0 = n1 = n2 = n3 = n4 = n5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!ray_done) { n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; }
-        if (at_leaf && cnt > 1) { n4 = p[4]; n5 = p[5]; }
-        if (at_node) {
-#else
+        const float4 n0 = f.n0, n1 = f.n1, n2 = f.n2, n3 = f.n3;
         if (!ray_done && cnt == 0) {
-            const float4 *n = S.nodes + 4 * (size_t)id;
-            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-#endif
             // slab distances on the node's quantisation grid: t = (origin + scale q - o) / d = q A + B
             const f3 A = mk3(n0.w * inv.x, n1.x * inv.y, n1.y * inv.z);
             const f3 B = mk3((n0.x - o.x) * inv.x, (n0.y - o.y) * inv.y, (n0.z - o.z) * inv.z);
@@ -266,25 +258,14 @@ struct BvhAccel {
                 w.sp = sp; w.id = next >> 3; w.cnt = next & 7;
                 return true;
             }
-#if ZDR_BVH_UNIFIED_FETCH
-        } else if (at_leaf) {
+        } else if (!ray_done) {
             float t;
             if (tri_test(n0, n1, n2, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id; }
-            if (cnt > 1 && tri_test(n3, n4, n5, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id + 1; }
+            if (cnt > 1 && tri_test(n3, f.n4, f.n5, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id + 1; }
             for (int s = id + 2; s < id + cnt; s++)       // leaves of more than two triangles (ZDR_BVH_LEAF > 2)
                 if (tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = s; }
             if (anyhit && w.h.slot >= 0) ray_done = true;         // any-hit: the first hit settles it
         }
-#else
-        } else if (!ray_done) {
-            for (int s = id; s < id + cnt; s++) {
-                float t;
-                bool ok = tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, w.h.t, t);
-                if (ok) { w.h.t = t; w.h.slot = s; }
-            }
-            if (anyhit && w.h.slot >= 0) ray_done = true;         // any-hit: the first hit settles it
-        }
-#endif
         if (!ray_done && w.sp != 0) {
             w.sp--;
             int e = (w.sp < LN) ? stack[w.sp * 64 + lane] : deep[w.sp - LN];
@@ -293,26 +274,30 @@ struct BvhAccel {
         }
         return false;
     }
+    ZD static bool step(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const bool anyhit) {
+        const Fetched f = fetch(S, w);
+        return consume(S, stack, LN, deep, w, f, anyhit);
+    }
     // One loop walks up to two rays per lane back to back: first (HAS_A) an any-hit ray — the shadow segment of a
     // path vertex — then (HAS_B, lanes with needB) a closest-hit ray — the continuation ray.  A lane starts its second
     // ray the moment its first one ends, so the wave's trip count is the longest SUM of the two walks over its
     // lanes, not the sum of the two longest walks.
     template <bool HAS_A, bool HAS_B>
     ZD static void walk(const DScene &S, int *stack, f3 oA, f3 dA, float tminA, float tmaxA,
-                        bool needB, f3 oB, f3 dB, float tminB, float tmaxB, bool &occ, Hit &hit) {
+                        bool needB, f3 oB, f3 dB, float tminB, float tmaxB, bool &occ, Hit &hit, bool needA = true) {
         occ = false;
         hit.slot = -1; hit.u = 0.0f; hit.v = 0.0f; hit.t = tmaxB;
-        if (!HAS_A && !needB) return;
-        bool first = HAS_A;                                  // this lane is still on its any-hit ray
+        if (!(HAS_A && needA) && !needB) return;
+        bool first = HAS_A && needA;                         // this lane is still on its any-hit ray
         const int LN = (S.stack_entries < ZDR_BVH_LDS_STACK) ? S.stack_entries : ZDR_BVH_LDS_STACK;
         int deep[ZDR_BVH_STACK - ZDR_BVH_LDS_STACK + 4];
         Walker w;
-        if (HAS_A) start(S, w, oA, dA, tminA, tmaxA); else start(S, w, oB, dB, tminB, tmaxB);
+        if (first) start(S, w, oA, dA, tminA, tmaxA); else start(S, w, oB, dB, tminB, tmaxB);
         for (;;) {
-            if (step(S, stack, LN, deep, w, HAS_A && first)) continue;
+            if (step(S, stack, LN, deep, w, first)) continue;
             // this lane's current ray has ended
             if (w.budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);   // the walk was cut short: whatever it returns is not a result
-            if (HAS_A && first) {
+            if (first) {
                 occ = w.h.slot >= 0;
                 if (!HAS_B || !needB) break;
                 first = false;
@@ -323,54 +308,6 @@ struct BvhAccel {
         }
         if (HAS_B && !first && needB) { hit = w.h; hit_barycentrics(S, hit, oB, dB); }
     }
-#if ZDR_BVH_RAY_POOL
-    // Both rays of a path vertex, with the CONTINUATION rays of the whole wave in a pool (LDS, after the traversal
-    // stacks): a lane traces its own shadow ray and then takes continuation rays from the pool — whoever they belong
-    // to — until none is left, so a lane whose own rays were short (or that has no vertex at all this trip:
-    // active == false) works on instead of waiting for the wave's longest pair of walks.
-    // Called by the whole wave from a reconverged point.  Pool (ints): [0] next ray, then o.x o.y o.z d.x d.y d.z [64]
-    // each; the result (slot, t) of ray k overwrites o.x[k], o.y[k] — only the lane that traced it had read them.
-    ZD static void walk_pool(const DScene &S, int *stack, bool active, f3 oA, f3 dA, float tminA, float tmaxA,
-                             bool needB, f3 oB, f3 dB, bool &occ, Hit &hit) {
-        occ = false;
-        hit.slot = -1; hit.u = 0.0f; hit.v = 0.0f; hit.t = 1e30f;
-        const int lane = threadIdx.x & 63;
-        const int LN = (S.stack_entries < ZDR_BVH_LDS_STACK) ? S.stack_entries : ZDR_BVH_LDS_STACK;
-        int *pool = stack + LN * 64;
-        float *pf = (float *)(pool + 1);
-        const unsigned long long here = __ballot(true), mB = __ballot(needB);
-        const int nB = __popcll(mB);
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
-        if (needB) { pf[rank] = oB.x; pf[64 + rank] = oB.y; pf[128 + rank] = oB.z; pf[192 + rank] = dB.x; pf[256 + rank] = dB.y; pf[320 + rank] = dB.z; }
-        if (lane == __builtin_ctzll(here)) pool[0] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        int deep[ZDR_BVH_STACK - ZDR_BVH_LDS_STACK + 4];
-        Walker w;
-        bool first = active;                                 // on the lane's own any-hit ray
-        bool have = active;
-        int cur = -1;                                        // pool ray in flight
-        if (active) start(S, w, oA, dA, tminA, tmaxA);
-        else { w.o = mk3(0.0f); w.d = mk3(0.0f, 0.0f, 1.0f); w.inv = mk3(0.0f); w.tmin = 0.0f; w.h.slot = -1; w.h.u = w.h.v = 0.0f; w.h.t = 0.0f; w.sp = 0; w.id = 0; w.cnt = 0; w.budget = 0; }
-        for (;;) {
-            if (!have) {
-                const int k = atomicAdd(&pool[0], 1);        // ds_add_rtn_u32
-                if (k >= nB) break;
-                cur = k; have = true;
-                start(S, w, mk3(pf[k], pf[64 + k], pf[128 + k]), mk3(pf[192 + k], pf[256 + k], pf[320 + k]), 0.0f, 1e30f);
-            }
-            if (step(S, stack, LN, deep, w, first)) continue;
-            if (w.budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);
-            if (first) { occ = w.h.slot >= 0; first = false; }
-            else { pool[1 + cur] = w.h.slot; pf[64 + cur] = w.h.t; }
-            have = false;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (needB) { hit.slot = pool[1 + rank]; hit.t = pf[64 + rank]; hit_barycentrics(S, hit, oB, dB); }
-        __builtin_amdgcn_wave_barrier();
-    }
-#endif
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         bool occ; Hit h;
         walk<false, true>(S, stack, o, d, tmin, tmax, true, o, d, tmin, tmax, occ, h);
@@ -381,13 +318,8 @@ struct BvhAccel {
         walk<true, false>(S, stack, o, d, tmin, tmax, false, o, d, tmin, tmax, occ, h);
         return occ;
     }
-    // Called by the whole wave (path_shade); `active`: this lane has a vertex, i.e. a shadow ray (o1, d1) and — if need2 — a continuation ray
-    ZD static void shadow_and_closest(const DScene &S, int *stack, bool active, f3 o1, f3 d1, float tmin1, float tmax1, bool need2, f3 o2, f3 d2, bool &occ, Hit &h) {
-#if ZDR_BVH_RAY_POOL
-        walk_pool(S, stack, active, o1, d1, tmin1, tmax1, need2, o2, d2, occ, h);
-#else
-        occ = false; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = 1e30f;
-        if (active) walk<true, true>(S, stack, o1, d1, tmin1, tmax1, need2, o2, d2, 0.0f, 1e30f, occ, h);
-#endif
+    // need1: the lane has a shadow ray (o1, d1) at all; need2: it has a continuation ray (o2, d2)
+    ZD static void shadow_and_closest(const DScene &S, int *stack, bool need1, f3 o1, f3 d1, float tmin1, float tmax1, bool need2, f3 o2, f3 d2, bool &occ, Hit &h) {
+        walk<true, true>(S, stack, o1, d1, tmin1, tmax1, need2, o2, d2, 0.0f, 1e30f, occ, h, need1);
     }
 };

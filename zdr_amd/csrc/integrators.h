@@ -26,7 +26,7 @@ ZD void pixel_ray(const RenderCfg &R, const SamplerCfg &C, Sampler &smp, int x, 
 }
 
 struct Counters { uint32_t c[8]; };
-enum { C_SAMPLES, C_CLOSEST, C_HITS, C_SHADOW, C_SHADED, C_EMIT_BSDF, C_NAN, C_UNUSED };
+enum { C_SAMPLES, C_CLOSEST, C_HITS, C_SHADOW, C_SHADED, C_EMIT_BSDF, C_NAN, C_SHADOW_TRACED };
 #define COUNT(i) do { if (STATS) cnt.c[i]++; } while (0)
 
 ZD f3 clamp_radiance(f3 r) { return mk3(clampf(r.x, 0.0f, 100000.0f), clampf(r.y, 0.0f, 100000.0f), clampf(r.z, 0.0f, 100000.0f)); }
@@ -236,53 +236,50 @@ ZD bool path_arrive(const DScene &S, PathState &ps, const Hit &h, Interaction &i
 // A::kFuseRays selects WHEN the shadow ray is traced:
 //   false (brute force)  shadow ray -> NEE -> BSDF sampling, as the reference; the continuation ray is traced by
 //                        path_continue, which the backward kernel calls once the vertex record has left the registers;
-//   true  (BVH)          BSDF sampling first, then both rays in ONE traversal loop (a lane starts its continuation
-//                        ray as soon as its shadow ray has ended), then the NEE contribution — which only needs
-//                        the throughput that ARRIVED at the vertex.
+//   true  (BVH)          NEE arithmetic and BSDF sampling first, then both rays in ONE traversal loop (a lane starts its
+//                        continuation ray as soon as its shadow ray has ended; no shadow ray at all when the light
+//                        sample carries nothing), then the NEE terms are added if the shadow ray came through.
 // BWD: fills pv, the record of this vertex.
 template <int SK, class A, bool BWD, bool STATS, bool ENV>
 ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                   PathState &ps, const Interaction &it, PathVertex &pv, Hit &h, Counters &cnt, bool active = true) {
-    // A::kFuseRays: the WHOLE wave calls this from a reconverged point and `active` says whether the lane has a vertex
-    // to shade — lanes without one still take part in the traversal (BvhAccel's ray pool: they trace other lanes'
-    // continuation rays).  Otherwise the caller only comes here with lanes that have a vertex.
-    float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    f3 diffuse = mk3(0.0f), wo = mk3(0.0f, 0.0f, 1.0f), wil = mk3(0.0f, 0.0f, 1.0f); float roughness = 1.0f;
-    Onb onb; onb.tangent = mk3(1.0f, 0.0f, 0.0f); onb.binormal = mk3(0.0f, 1.0f, 0.0f); onb.normal = mk3(0.0f, 0.0f, 1.0f);
-    LightSample light; light.wi = mk3(0.0f, 0.0f, 1.0f); light.dist = 0.0f; light.pdf = 1.0f; light.eval = mk3(0.0f);
-    if (active) {
-        m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
-        diffuse = mk3(m.x, m.y, m.z); roughness = m.w;
-        COUNT(C_SHADED);
-        if (BWD) {
-            pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
-            pv.T = mk3(0.0f); pv.fLW = mk3(0.0f); pv.bnorm = mk3(0.0f); pv.neeM = mk3(0.0f); pv.dlnp = 0.0f; pv.rr = 0;
-        }
-        onb = make_onb(it.ns);
-        wo = to_local(onb, -ps.d);
-        // next-event estimation: the light sample (prb.py:57-58)
-        float u_pick = sampler_next<SK>(C, ps.smp);
-        light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
-        wil = to_local(onb, light.wi);
+                   PathState &ps, const Interaction &it, PathVertex &pv, Hit &h, Counters &cnt) {
+    float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
+    f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
+    COUNT(C_SHADED);
+    if (BWD) {
+        pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
+        pv.T = mk3(0.0f); pv.fLW = mk3(0.0f); pv.bnorm = mk3(0.0f); pv.neeM = mk3(0.0f); pv.dlnp = 0.0f; pv.rr = 0;
     }
+    Onb onb = make_onb(it.ns);
+    f3 wo = to_local(onb, -ps.d);
+    // next-event estimation: the light sample (prb.py:57-58)
+    float u_pick = sampler_next<SK>(C, ps.smp);
+    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
+    const f3 wil = to_local(onb, light.wi);
 
-    auto nee = [&](bool occluded, f3 beta_in) {                                   // prb.py:60-66; beta_in: throughput arriving at the vertex
-        if (!occluded && wil.z >= 1e-4f) {
-            GgxTerms g = ggx_terms(wo, wil, roughness);
-            f3 bsdf = ggx_brdf_from(g, wil, diffuse);
-            float pb = ggx_pdf_from(g, wo, wil);
-            float mis = balanced_heuristic(light.pdf, pb);
-            float inv_dn = rcp(fmaxf(light.pdf, 1e-4f));
-            ps.L = ps.L + (((beta_in * bsdf) * mis) * light.eval) * inv_dn;
-            if (BWD) {
-                f3 W = (light.eval * mis) * inv_dn;
-                float dlnpL;
-                pv.bW = beta_in * W; pv.cL = wil.z * ZDR_INV_PI; pv.dfLdr = ggx_dfdr_from(g, wo, wil, roughness, dlnpL);
-                pv.fLW = bsdf * W;
-                float pbf = (light.pdf + pb > 1e-4f) ? pb * rcp(light.pdf + pb) : 0.0f;   // d w_nee/dr = -w_nee pb/(pl+pb) dln(pb)/dr
-                pv.neeM = ((beta_in * bsdf) * W) * (pbf * dlnpL);
-            }
+    // The light sample's contribution AS IF it were unoccluded (prb.py:60-66); applied once the shadow ray is known to be free.
+    struct NeeTerms { f3 dL, bW, fLW, neeM; float cL, dfLdr; };
+    auto nee_terms = [&](f3 beta_in) {                                            // beta_in: throughput arriving at the vertex
+        NeeTerms n; n.dL = n.bW = n.fLW = n.neeM = mk3(0.0f); n.cL = 0.0f; n.dfLdr = 0.0f;
+        GgxTerms g = ggx_terms(wo, wil, roughness);
+        f3 bsdf = ggx_brdf_from(g, wil, diffuse);
+        float pb = ggx_pdf_from(g, wo, wil);
+        float mis = balanced_heuristic(light.pdf, pb);
+        float inv_dn = rcp(fmaxf(light.pdf, 1e-4f));
+        n.dL = (((beta_in * bsdf) * mis) * light.eval) * inv_dn;
+        if (BWD) {
+            f3 W = (light.eval * mis) * inv_dn;
+            float dlnpL;
+            n.bW = beta_in * W; n.cL = wil.z * ZDR_INV_PI; n.dfLdr = ggx_dfdr_from(g, wo, wil, roughness, dlnpL);
+            n.fLW = bsdf * W;
+            float pbf = (light.pdf + pb > 1e-4f) ? pb * rcp(light.pdf + pb) : 0.0f;   // d w_nee/dr = -w_nee pb/(pl+pb) dln(pb)/dr
+            n.neeM = ((beta_in * bsdf) * W) * (pbf * dlnpL);
         }
+        return n;
+    };
+    auto nee_apply = [&](const NeeTerms &n) {
+        ps.L = ps.L + n.dL;
+        if (BWD) { pv.bW = n.bW; pv.cL = n.cL; pv.dfLdr = n.dfLdr; pv.fLW = n.fLW; pv.neeM = n.neeM; }
     };
     auto sample_bsdf = [&]() -> bool {                                            // prb.py:69-87; true = the path stops here
         float u_lobe = sampler_next<SK>(C, ps.smp);
@@ -326,20 +323,33 @@ ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, con
         return stop;
     };
 
-    bool stop = true;
+    COUNT(C_SHADOW);
+    bool stop;
     if constexpr (A::kFuseRays) {
-        const f3 beta_arrived = ps.beta;
-        if (active) {
-            COUNT(C_SHADOW);
-            stop = sample_bsdf();
-            if (!stop) COUNT(C_CLOSEST);
+        // The NEE arithmetic comes first, so that only its results (not the frame, the light sample and the material) have
+        // to live through the traversal — and so that the shadow ray can be SKIPPED when nothing rides on it: a light
+        // sample below the horizon (prb.py:62) or one that carries exactly nothing even if visible (a light seen from
+        // behind or edge-on has eval = 0, light.py:76).  On the Cornell box that is every vertex of the ceiling.  Exact:
+        // only all-zero, NaN-free terms are dropped, so the image and the gradients are the reference's bit for bit.
+        NeeTerms n; n.dL = n.bW = n.fLW = n.neeM = mk3(0.0f); n.cL = 0.0f; n.dfLdr = 0.0f;
+        bool shadow = wil.z >= 1e-4f;
+        if (shadow) {
+            n = nee_terms(ps.beta);
+            const bool nothing = (n.dL.x == 0.0f) & (n.dL.y == 0.0f) & (n.dL.z == 0.0f) &&
+                                 (!BWD || ((n.bW.x == 0.0f) & (n.bW.y == 0.0f) & (n.bW.z == 0.0f) & (n.fLW.x == 0.0f) & (n.fLW.y == 0.0f) & (n.fLW.z == 0.0f) &
+                                           (n.neeM.x == 0.0f) & (n.neeM.y == 0.0f) & (n.neeM.z == 0.0f) & (fabsf(n.dfLdr) < 3.0e38f)));
+            shadow = !nothing;
         }
-        bool occluded = false;
-        A::shadow_and_closest(S, lds, active, it.p, light.wi, 1e-4f, light.dist, active && !stop, ps.o, ps.d, occluded, h);
-        if (active) nee(occluded, beta_arrived);
+        if (shadow) COUNT(C_SHADOW_TRACED);                                               // counter 7: shadow rays actually traced
+        stop = sample_bsdf();
+        if (!stop) COUNT(C_CLOSEST);
+        bool occluded;
+        A::shadow_and_closest(S, lds, shadow, it.p, light.wi, 1e-4f, light.dist, !stop, ps.o, ps.d, occluded, h);
+        if (shadow && !occluded) nee_apply(n);
     } else {
-        COUNT(C_SHADOW);
-        nee(A::any(S, lds, it.p, light.wi, 1e-4f, light.dist), ps.beta);
+        const bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
+        if (!occluded && wil.z >= 1e-4f) nee_apply(nee_terms(ps.beta));
+        COUNT(C_SHADOW_TRACED);
         stop = sample_bsdf();              // the caller traces the continuation ray (path_continue), after it has put pv away
     }
     return stop;

@@ -226,11 +226,9 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesFwd) void k_path(DScene S, Render
         if (__ballot(alive) != 0ull) {
             progress = true;
             bool done = false;
-            Hit h; h.slot = -1; h.u = h.v = h.t = 0.0f;
-            // BvhAccel traces the wave's rays together (ray pool): lanes without a vertex take part in the traversal
-            if constexpr (A::kFuseRays) done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt, alive) && alive;
             if (alive) {
-                if constexpr (!A::kFuseRays) done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
+                Hit h;
+                done = path_shade<SK, A, false, STATS, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
                 if (!done) { path_continue<A, STATS>(S, lds, ps, h, cnt); done = path_arrive<false, STATS, ENV>(S, ps, h, it, term_Li, cnt); }
                 if (done) {
                     alive = false;
@@ -348,11 +346,10 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             plast.a = plast.b = plast.c = plast.d = plast.e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             int sw_k = -1;                                  // next vertex the sweep consumes
             SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
-            PathVertex pv; Hit h; h.slot = -1; h.u = h.v = h.t = 0.0f;
-            if constexpr (A::kFuseRays) done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt, alive) && alive;
             if (alive) {
-                float term_plfrac = 0.0f;
-                if constexpr (!A::kFuseRays) done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
+                PathVertex pv; float term_plfrac = 0.0f;
+                Hit h;
+                done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
                 plast = pack_vertex(pv, le_grad);
                 if (nrec < lds_vertices) plast.e = make_float4(0.0f, 0.0f, 0.0f, plast.e.w);   // LDS records carry no RR fields
                 if (!done) { path_continue<A, false>(S, lds, ps, h, cnt); done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac); }
@@ -513,10 +510,8 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 }
 
 // ----------------------------------------------------------------------------------- launch
-// dynamic LDS of a wave that traverses the BVH: the per-lane stacks and, behind them, the continuation-ray pool (accel.h)
-static size_t bvh_dyn_lds(const DScene &S) {
-    return ((size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE + (ZDR_BVH_RAY_POOL ? 1 + 6 * WAVE : 0)) * sizeof(int);
-}
+// dynamic LDS of a wave that traverses the BVH: the first entries of the per-lane stacks (accel.h)
+static size_t bvh_dyn_lds(const DScene &S) { return (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int); }
 // Persistent grid of the path kernels: as many single-wave workgroups as the chip holds at once (never more
 // than there are items).  A workgroup that is not resident at first simply starts later and draws what is left.
 template <class K>

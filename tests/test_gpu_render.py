@@ -367,3 +367,29 @@ def test_a_tripped_watchdog_is_reported_not_swallowed(mat_a, monkeypatch):
     bad.render_backward(torch.ones((32, 32, 4), device="cuda"), g, m, (32, 32), 4, 0)
     with pytest.raises(ZdrError, match="incomplete"):
         bad.render_stats(m, (32, 32), 4)                          # the stats call checks by itself
+
+
+@pytest.mark.parametrize("tex", [(1, 1), (2, 2), (4, 4), (5, 3), (8, 8), (16, 16), (40, 24)])
+@pytest.mark.parametrize("integrator", ["path", "direct"])
+def test_few_texels_gradient_matches_oracle(tex, integrator, cbox_oracle):
+    """README.md:21 of the reference: gradients that concentrate on few texels.  The kernels then keep the whole
+    staging-cell array in LDS (<= 28 cells) or add into replicated cell arrays (scene.h); both are re-associations of
+    the same sum.  (tex_h, tex_w) from a constant material (1 x 1) over non-square ones; float32 accumulators that
+    receive every term of the launch are where the unreduced scatter lost 40 % of the sum."""
+    th, tw = tex
+    rng = np.random.default_rng(th * 100 + tw)
+    mat = np.empty((th, tw, 4), np.float32)
+    mat[..., :3] = rng.uniform(0.2, 0.8, (th, tw, 3)); mat[..., 3] = rng.uniform(0.6, 1.0, (th, tw))
+    scene = make_scene(integrator)
+    W, spp, seed = 96, 16, 4
+    cot = rng.uniform(0.5, 1.5, (W, W, 4)).astype(np.float32)
+    m = torch.from_numpy(mat).cuda()
+    g = torch.zeros_like(m)
+    scene.render_backward(torch.from_numpy(cot).cuda(), g, m, (W, W), spp, seed)
+    scene.check()
+    ref = cbox_oracle.render_backward(oracle_params(scene, W, W, spp, seed + 1, mat.shape[:2]), cot, mat)
+    got = g.cpu().numpy()
+    # every texel holds thousands of contributions: compare texel by texel (the larger textures may show a flipped path)
+    bad = np.abs(got - ref) > 2e-3 * np.abs(ref) + 2e-4 * np.abs(ref).max()
+    assert bad.sum() <= (0 if th * tw <= 64 else 2e-3 * bad.size), (int(bad.sum()), np.abs(got - ref).max())
+    assert abs(got.sum() - ref.sum()) <= 3e-4 * abs(ref.sum())

@@ -119,18 +119,42 @@ ZD float4 read_bsdf(const float4 *__restrict__ mat, f2 uv, int tex_h, int tex_w)
 #endif
 static_assert(ZDR_SCATTER_CAP >= 64, "one push can add an entry per lane");
 
+//  * Few texels (README.md:21 of the reference: "atomic_fetch_add will become extremely slow" when the gradients
+//    concentrate on few texels — a constant or low-resolution material).  Every atomic of the launch then lands on a
+//    handful of addresses, which the memory-side atomic units serialise: measured on cbox 512^2 spp 256, 64x64 texels
+//    34 ms, 16x16 101 ms, 4x4 952 ms, 1x1 4.9 s instead of 17 ms — and one float32 accumulator that receives 1e8 terms
+//    is off by 40 %.  Two measures, both exact re-associations of the same sum:
+//      - cell COPIES: below 2^16 cells the staging array is replicated (up to 1024 times, 2^20 cells in all) and a
+//        wave adds into copy blockIdx % copies; k_cells_to_grad sums the copies (in float64);
+//      - at most ZDR_LDS_CELLS cells (textures up to 4x4): the wave keeps the WHOLE cell array in LDS (the queue's
+//        block), adds with ds_add_f32 and writes it out once, when the kernel ends.
+#define ZDR_LDS_CELLS 28             // 28 cells x 16 floats = the 448 floats of the queue's LDS block
+#define ZDR_MAX_CELL_COPIES 1024
 struct ScatterQueue {                // pointers into this wave's LDS block
     int *cell; float *g; float *ox; float *oy;
     int count;                       // wave-uniform
+    int copy_base;                   // first cell of this wave's copy of the staging array
+    int ncells;                      // (tex_h + 1) x (tex_w + 1)
+    float *lds_cells;                // != nullptr: the whole cell array lives here (ncells <= ZDR_LDS_CELLS)
 };
+#define ZDR_SCATTER_LDS_FLOATS (7 * ZDR_SCATTER_CAP)
+static_assert(16 * ZDR_LDS_CELLS <= ZDR_SCATTER_LDS_FLOATS, "the LDS cell array aliases the queue's block");
 
-ZD ScatterQueue scatter_queue_init(float *lds) {
+// must be called by the whole wave
+ZD ScatterQueue scatter_queue_init(float *lds, int tex_h, int tex_w, int cell_copies) {
     ScatterQueue q;
     q.cell = (int *)lds; q.g = lds + ZDR_SCATTER_CAP; q.ox = lds + 5 * ZDR_SCATTER_CAP; q.oy = lds + 6 * ZDR_SCATTER_CAP;
     q.count = 0;
+    q.ncells = (tex_h + 1) * (tex_w + 1);
+    q.copy_base = (int)(blockIdx.x % (unsigned)cell_copies) * q.ncells;
+    q.lds_cells = (q.ncells <= ZDR_LDS_CELLS) ? lds : nullptr;
+    if (q.lds_cells) {
+        for (int i = threadIdx.x & 63; i < 16 * q.ncells; i += 64) lds[i] = 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     return q;
 }
-#define ZDR_SCATTER_LDS_FLOATS (7 * ZDR_SCATTER_CAP)
 
 // must be called by the whole wave (reconverged control flow)
 ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells) {
@@ -152,20 +176,46 @@ ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells) {
     q.count = 0;
 }
 
+// end of the kernel: whatever is still queued, and the LDS cell array if the wave kept one
+ZD void scatter_finish(ScatterQueue &q, float *__restrict__ cells) {
+    scatter_flush(q, cells);
+    if (q.lds_cells) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = threadIdx.x & 63; i < 16 * q.ncells; i += 64) {
+            const float v = q.lds_cells[i];
+            if (v != 0.0f) unsafeAtomicAdd(cells + 16 * (size_t)q.copy_base + i, v);
+        }
+    }
+}
+
 // must be called by the whole wave; lanes with active == false push nothing
 ZD void scatter_push(ScatterQueue &q, float *__restrict__ cells, bool active, f2 uv, float4 g, int tex_h, int tex_w, int ablate) {
     if (ablate == 1) { asm volatile("" ::"v"(g.x), "v"(g.y), "v"(g.z), "v"(g.w), "v"(uv.x), "v"(uv.y)); return; }
     unsigned long long mask = __ballot(active);
     int n = __popcll(mask);
     if (n == 0) return;
+    float px = uv.x * (float)(tex_w - 1), py = (1.0f - uv.y) * (float)(tex_h - 1);   // interaction.py:78-80
+    int ix = (int)px, iy = (int)py;
+    float ox = px - (float)ix, oy = py - (float)iy;
+    int cx = clampi(ix, -1, tex_w - 1) + 1, cy = clampi(iy, -1, tex_h - 1) + 1;
+    const int cell = cx + (tex_w + 1) * cy;
+    if (q.lds_cells) {                   // few texels: the cell array is in LDS, 16 ds_add_f32 per vertex
+        if (active) {
+            float *c = q.lds_cells + 16 * cell;
+            const float k00 = (1.0f - ox) * (1.0f - oy), k01 = (1.0f - ox) * oy, k10 = ox * (1.0f - oy), k11 = ox * oy;   // corner m = 2 dx + dy
+            const float gg[4] = {g.x, g.y, g.z, g.w}, kk[4] = {k00, k01, k10, k11};
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++) __hip_atomic_fetch_add(c + 4 * m + ch, kk[m] * gg[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        return;
+    }
     if (q.count + n > ZDR_SCATTER_CAP) scatter_flush(q, cells);
     if (active) {
-        float px = uv.x * (float)(tex_w - 1), py = (1.0f - uv.y) * (float)(tex_h - 1);   // interaction.py:78-80
-        int ix = (int)px, iy = (int)py;
-        float ox = px - (float)ix, oy = py - (float)iy;
-        int cx = clampi(ix, -1, tex_w - 1) + 1, cy = clampi(iy, -1, tex_h - 1) + 1;
         int slot = q.count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        q.cell[slot] = (ablate == 2) ? ((cx + (tex_w + 1) * cy) & 1023) : (cx + (tex_w + 1) * cy);   // ablation 2: all atomics hit 64 KiB of L2
+        q.cell[slot] = (ablate == 2) ? (cell & 1023) : (q.copy_base + cell);   // ablation 2: all atomics hit 64 KiB of L2
         q.g[4 * slot] = g.x; q.g[4 * slot + 1] = g.y; q.g[4 * slot + 2] = g.z; q.g[4 * slot + 3] = g.w;
         q.ox[slot] = ox; q.oy[slot] = oy;
     }

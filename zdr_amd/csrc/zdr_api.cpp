@@ -597,6 +597,10 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     R.width = p->width; R.height = p->height; R.x0 = p->x0; R.y0 = p->y0; R.x1 = p->x1; R.y1 = p->y1;
     R.sample_begin = p->sample_begin; R.sample_end = p->sample_end;
     R.use_tent = p->use_tent; R.max_depth = p->max_depth; R.rr_depth = p->rr_depth; R.tex_h = p->tex_h; R.tex_w = p->tex_w;
+    {   // few texels: replicate the staging cells so that the launch's atomics do not pile up on a handful of addresses (scene.h)
+        const size_t ncells = (size_t)(p->tex_h + 1) * (size_t)(p->tex_w + 1);
+        R.cell_copies = (ncells < (1u << 16)) ? (int32_t)std::min<size_t>(ZDR_MAX_CELL_COPIES, (1u << 20) / ncells) : 1;
+    }
     R.two_over_w = 2.0f / (float)p->width; R.two_over_h = 2.0f / (float)p->height;
     R.aspect = (float)p->height / (float)p->width;
     R.inv_spp = 1.0f / (float)p->spp;
@@ -661,7 +665,7 @@ static int ensure_ring(zdr_scene *s, hipStream_t st) {
 }
 
 static int ensure_cells(zdr_scene *s, const RenderCfg &R, hipStream_t st) {
-    size_t need = (size_t)(R.tex_h + 1) * (R.tex_w + 1) * 16 * sizeof(float);
+    size_t need = (size_t)R.cell_copies * (size_t)(R.tex_h + 1) * (R.tex_w + 1) * 16 * sizeof(float);
     if (need > s->cells_bytes) {
         (void)hipFree(s->d_cells); s->d_cells = nullptr; s->cells_bytes = 0;
         HIPCHK(hipMalloc((void **)&s->d_cells, need));

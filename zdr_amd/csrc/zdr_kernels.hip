@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
     uint32_t next_sample = 0, s_end = 0, perm_seed = 0;
     unsigned long long cam_mask = 0ull;
     f3 le_grad = mk3(0.0f);                                 // cotangent of the running path's pixel
-    ScatterQueue q = scatter_queue_init(lds_q);
+    ScatterQueue q = scatter_queue_init(lds_q, R.tex_h, R.tex_w, R.cell_copies);
     PackedVertex deep[ZDR_MAX_RECORDED_DEPTH];
     int nrec = 0;
     PrimaryQueue pq = queue_init(io);
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
         stall = progress ? 0 : stall + 1;
         if (stall > 4) { raise_device_error(S, ZDR_DEVERR_STALL); break; }   // cannot happen (every branch above makes progress); never spin on the GPU, never end silently
     }
-    scatter_flush(q, io.cells);
+    scatter_finish(q, io.cells);
 }
 
 // ---------------------------------------------------------------------- direct / collocated
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerC
     for (int i = 0; i < 8; i++) cnt.c[i] = 0;
     f3 le_grad = mk3(0.0f);
     if (BWD) le_grad = load_le_grad(C, io, w);
-    ScatterQueue q = scatter_queue_init(lds_q);
+    ScatterQueue q = scatter_queue_init(lds_q, R.tex_h, R.tex_w, R.cell_copies);
     const unsigned long long cam_mask = camera_mask(S, io, w);
     f3 sum = mk3(0.0f);
     for (uint32_t it = w.s_begin; it < w.s_end; it++) {     // integrator.py:15 (wave-uniform trip count)
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerC
         }
         if (BWD) scatter_push(q, io.cells, w.valid && any_nonzero4(grad) && !any_nan4(grad), guv, grad, R.tex_h, R.tex_w, R.debug_no_scatter);
     }
-    if (BWD) scatter_flush(q, io.cells);
+    if (BWD) scatter_finish(q, io.cells);
     if (!BWD && !STATS) store_pixel(R, C, io, w, sum);
     flush_counters<STATS>(io, cnt);
 }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerC
 // Folds the staging cells into the gradient texture: texel (x, y) receives corner (dx, dy) of every
 // cell (ix, iy) with clamp(ix + dx) == x and clamp(iy + dy) == y — the adjoint of read_bsdf's CLAMP
 // bilinear lookup (interaction.py:47-60, 73-89).  Deterministic summation order.
-__global__ void k_cells_to_grad(const float4 *__restrict__ cells, float4 *__restrict__ dmat, int tex_h, int tex_w) {
+__global__ void k_cells_to_grad(const float4 *__restrict__ cells, float4 *__restrict__ dmat, int tex_h, int tex_w, int copies) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= tex_w) return;
     int ixs[3], dxs[3], nx = 0, iys[3], dys[3], ny = 0;
@@ -456,12 +456,25 @@ __global__ void k_cells_to_grad(const float4 *__restrict__ cells, float4 *__rest
     if (y == 0) { iys[ny] = -1; dys[ny++] = 0; }
     if (y == tex_h - 1) { iys[ny] = tex_h - 1; dys[ny++] = 1; }
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int b = 0; b < ny; b++)
-        for (int a = 0; a < nx; a++) {
-            size_t cell = (size_t)(ixs[a] + 1) + (size_t)(tex_w + 1) * (iys[b] + 1);
-            float4 c = cells[4 * cell + 2 * dxs[a] + dys[b]];
-            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
-        }
+    const size_t ncells = (size_t)(tex_h + 1) * (tex_w + 1);
+    if (copies == 1) {
+        for (int b = 0; b < ny; b++)
+            for (int a = 0; a < nx; a++) {
+                size_t cell = (size_t)(ixs[a] + 1) + (size_t)(tex_w + 1) * (iys[b] + 1);
+                float4 c = cells[4 * cell + 2 * dxs[a] + dys[b]];
+                acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+            }
+    } else {   // few texels: the waves added into `copies` replicas of the cell array (scene.h); sum them in float64
+        double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+        for (int k = 0; k < copies; k++)
+            for (int b = 0; b < ny; b++)
+                for (int a = 0; a < nx; a++) {
+                    size_t cell = (size_t)k * ncells + (size_t)(ixs[a] + 1) + (size_t)(tex_w + 1) * (iys[b] + 1);
+                    float4 c = cells[4 * cell + 2 * dxs[a] + dys[b]];
+                    sx += c.x; sy += c.y; sz += c.z; sw += c.w;
+                }
+        acc = make_float4((float)sx, (float)sy, (float)sz, (float)sw);
+    }
     float4 d = dmat[(size_t)x + (size_t)tex_w * y];
     dmat[(size_t)x + (size_t)tex_w * y] = make_float4(d.x + acc.x, d.y + acc.y, d.z + acc.z, d.w + acc.w);
 }
@@ -589,7 +602,7 @@ int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     }
     if (backward) {   // fold the staging cells into d_material (+=)
         dim3 g((R.tex_w + 63) / 64, R.tex_h);
-        hipLaunchKernelGGL(k_cells_to_grad, g, dim3(64), 0, st, (const float4 *)io.cells, (float4 *)io.d_material, R.tex_h, R.tex_w);
+        hipLaunchKernelGGL(k_cells_to_grad, g, dim3(64), 0, st, (const float4 *)io.cells, (float4 *)io.d_material, R.tex_h, R.tex_w, R.cell_copies);
     }
     if (!backward && !stats && R.nchunks > 1) {
         dim3 g((R.x1 - R.x0 + 63) / 64, R.y1 - R.y0);

@@ -33,7 +33,7 @@ def build(A, accel):
     assert rc == 0, _native.lib().zdr_last_error()
     global STACK
     STACK = se.value                          # what the kernels allocate in LDS for this tree
-    assert 8 <= STACK <= 48 and STACK % 4 == 0
+    assert 8 <= STACK <= 64 and STACK % 4 == 0
     return nodes[:nn.value], order, isect
 
 
@@ -48,17 +48,20 @@ def tri_test(q, o, d, tmin, tmax):
     return bool(t > tmin and t < tmax and u >= 0 and v >= 0 and u + v <= 1), t
 
 
-def qbox_entry(k, q, A, B, tmin, tmax):
-    """mirror of qbox_entry<K>: q = (lxq, lyq, lzq, hxq, hyq, hzq) words, byte k belongs to child k; t = q A + B in float32"""
+def qbox_entry(k, q, A, B, tmin, tmax, inv):
+    """mirror of qbox_entry<K>: q = (lxq, lyq, lzq, hxq, hyq, hzq) words, byte k belongs to child k; t = q A + B in float32.
+    Per axis the ray enters through the low plane when its direction is positive, else through the high plane."""
     f = np.float32
     ql = np.array([(int(q[a]) >> (8 * k)) & 255 for a in range(3)], np.float32)
     qh = np.array([(int(q[3 + a]) >> (8 * k)) & 255 for a in range(3)], np.float32)
+    neg = inv < 0
+    qn, qf = np.where(neg, qh, ql), np.where(neg, ql, qh)
     with np.errstate(invalid="ignore", over="ignore"):
         # fmaf: one rounding; float64 product + sum rounded once is exact enough to mirror it (24 x 8 bit product is exact)
-        t0 = (ql.astype(np.float64) * A.astype(np.float64) + B.astype(np.float64)).astype(f)
-        t1 = (qh.astype(np.float64) * A.astype(np.float64) + B.astype(np.float64)).astype(f)
-    tn = max(np.fmax.reduce(np.fmin(t0, t1)), tmin)      # fmin/fmax drop NaNs like v_min_f32 / v_max_f32
-    tf = min(np.fmin.reduce(np.fmax(t0, t1)), tmax)
+        tnear = (qn.astype(np.float64) * A.astype(np.float64) + B.astype(np.float64)).astype(f)
+        tfar = (qf.astype(np.float64) * A.astype(np.float64) + B.astype(np.float64)).astype(f)
+    tn = np.fmax(np.fmax.reduce(tnear), tmin)            # fmin/fmax drop NaNs like v_min_f32 / v_max_f32
+    tf = np.fmin(np.fmin.reduce(tfar), tmax)
     return tn if tn <= tf else 3.0e38
 
 
@@ -90,7 +93,7 @@ def traverse(nodes, isect, o, d, tmin, tmax, any_hit):
             origin, scale, q, p = decode_node(nodes[nid])
             with np.errstate(invalid="ignore", over="ignore"):
                 A = (scale * inv).astype(np.float32); B = ((origin - o) * inv).astype(np.float32)
-            e = [qbox_entry(c, q, A, B, tmin, best_t) if (p[c] & 7) != 7 else 3.0e38 for c in range(4)]
+            e = [qbox_entry(c, q, A, B, tmin, best_t, inv) if (p[c] & 7) != 7 else 3.0e38 for c in range(4)]
             em = min(e)
             if em < 2.0e38:
                 nxt, taken = -1, [False] * 4

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k(const float4 *__restrict__ rec, uint32_t
             }
         }
         acc += n0.x + n1.y + n2.z;
-        idx = __float_as_uint(n3.w) & mask;                  // the next record: known only now
+        idx = hash32(idx + 0x9e3779b9u * (uint32_t)(v + 1) + __float_as_uint(n3.w)) & mask;   // the next record: known only now (and not a walk of a fixed random map, whose orbits merge)
     }
     out[blockIdx.x * 64 + lane] = acc;
 }

@@ -152,18 +152,21 @@ struct BruteAccel {
     }
 };
 
-// slab test against child K of a quantised node (byte K of each q word); returns the entry distance, or 3e38 on a miss.
-// fminf/fmaxf drop NaNs (0 * inf when a direction component is 0), which keeps the test conservative.
+// Slab test against child K of a quantised node (byte K of each q word); returns the entry distance, or 3e38 on a miss.
+// nq / fq: per axis the word of the planes the ray ENTERS through and the one it LEAVES through — chosen once per node
+// from the sign of the direction (for all four children at once), so a child costs six conversions, three packed FMAs
+// {near, far} = q {A, A} + {B, B}, one max3 / min3 pair with the ray interval and a compare (25 -> 17 VALU; the BVH
+// kernels are VALU-issue-bound).  fminf / fmaxf drop NaNs (0 * inf when a direction component is 0): an axis that cannot
+// be decided is ignored, which keeps the test conservative.
 template <int K> ZD float ubyte(uint32_t w) {
     return (float)((w >> (8 * K)) & 0xffu);              // v_cvt_f32_ubyteK
 }
 template <int K>
-ZD float qbox_entry(uint32_t lxq, uint32_t lyq, uint32_t lzq, uint32_t hxq, uint32_t hyq, uint32_t hzq, f3 A, f3 B, float tmin, float tmax) {
-    float t0x = fmaf(ubyte<K>(lxq), A.x, B.x), t1x = fmaf(ubyte<K>(hxq), A.x, B.x);
-    float t0y = fmaf(ubyte<K>(lyq), A.y, B.y), t1y = fmaf(ubyte<K>(hyq), A.y, B.y);
-    float t0z = fmaf(ubyte<K>(lzq), A.z, B.z), t1z = fmaf(ubyte<K>(hzq), A.z, B.z);
-    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+ZD float qbox_entry(uint32_t nxq, uint32_t nyq, uint32_t nzq, uint32_t fxq, uint32_t fyq, uint32_t fzq, f3 A, f3 B, float tmin, float tmax) {
+    v2f qx = {ubyte<K>(nxq), ubyte<K>(fxq)}, qy = {ubyte<K>(nyq), ubyte<K>(fyq)}, qz = {ubyte<K>(nzq), ubyte<K>(fzq)};
+    v2f tx = pfma(qx, splat(A.x), splat(B.x)), ty = pfma(qy, splat(A.y), splat(B.y)), tz = pfma(qz, splat(A.z), splat(B.z));
+    float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+    float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
     return (tn <= tf) ? tn : 3.0e38f;
 }
 
@@ -223,11 +226,16 @@ struct BvhAccel {
             const uint32_t lxq = __float_as_uint(n1.z), lyq = __float_as_uint(n1.w), lzq = __float_as_uint(n2.x);
             const uint32_t hxq = __float_as_uint(n2.y), hyq = __float_as_uint(n2.z), hzq = __float_as_uint(n2.w);
             const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), c2 = __float_as_uint(n3.z), c3 = __float_as_uint(n3.w);
-            // count == 7 marks an unused child slot (a slab test cannot express "never hit")
-            float e0 = ((c0 & 7u) != 7u) ? qbox_entry<0>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, w.h.t) : 3.0e38f;
-            float e1 = ((c1 & 7u) != 7u) ? qbox_entry<1>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, w.h.t) : 3.0e38f;
-            float e2 = ((c2 & 7u) != 7u) ? qbox_entry<2>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, w.h.t) : 3.0e38f;
-            float e3 = ((c3 & 7u) != 7u) ? qbox_entry<3>(lxq, lyq, lzq, hxq, hyq, hzq, A, B, tmin, w.h.t) : 3.0e38f;
+            // the planes the ray enters / leaves through, for the four children at once
+            const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
+            const uint32_t nxq = ngx ? hxq : lxq, fxq = ngx ? lxq : hxq, nyq = ngy ? hyq : lyq, fyq = ngy ? lyq : hyq, nzq = ngz ? hzq : lzq, fzq = ngz ? lzq : hzq;
+            float e0 = qbox_entry<0>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
+            float e1 = qbox_entry<1>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
+            float e2 = qbox_entry<2>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
+            float e3 = qbox_entry<3>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
+            // count == 7 marks an unused child slot (a slab test cannot express "never hit" for a ray full of NaNs): selects, not branches
+            e0 = ((c0 & 7u) != 7u) ? e0 : 3.0e38f; e1 = ((c1 & 7u) != 7u) ? e1 : 3.0e38f;
+            e2 = ((c2 & 7u) != 7u) ? e2 : 3.0e38f; e3 = ((c3 & 7u) != 7u) ? e3 : 3.0e38f;
             int p0 = (int)c0, p1 = (int)c1, p2 = (int)c2, p3 = (int)c3;
             // nearest child: visit now; the other hit children go on the stack.  On the fast path the four
             // stack writes are unconditional (LDS stores are cheap, branches are not): a slot is kept only

@@ -4,7 +4,7 @@
 #pragma once
 #include "vecmath.h"
 
-#define ZDR_BVH_STACK 48   // upper bound of per-lane traversal stack entries; the builder bounds the tree depth below it
+#define ZDR_BVH_STACK 64   // upper bound of per-lane traversal stack entries; the builder bounds the tree depth below it
 #ifndef ZDR_BVH_LDS_STACK
 #define ZDR_BVH_LDS_STACK 8    // of which this many live in LDS (the rest, rarely reached, in scratch); 1 M triangles, fwd / bwd ms: 44 (all) 94 / 149, 16: 92 / 115, 12: 91 / 115, 8: 93 / 108
 #endif

@@ -33,6 +33,7 @@ enum { ZDR_COLLOCATED = 0, ZDR_DIRECT = 1, ZDR_PATH = 2, ZDR_UVGRAD = 3 };
 enum { ZDR_SAMPLER_CMJ = 0, ZDR_SAMPLER_PMJ02BN = 1 };
 /* acceleration structure used for LuisaCompute's Accel (render.py:74,109,127) */
 enum { ZDR_ACCEL_AUTO = 0, ZDR_ACCEL_BRUTE = 1, ZDR_ACCEL_BVH = 2 };
+enum { ZDR_PRB_EXPECTATION = 0, ZDR_PRB_DETACHED = 1 };
 
 typedef struct zdr_scene zdr_scene;
 
@@ -60,6 +61,13 @@ typedef struct {
      * congruent to tile_shard_index modulo tile_shard_count — one launch per rank, every rank sees every part of the
      * image (load balance).  tile_shard_count <= 1: the whole rectangle. */
     int32_t tile_shard_index, tile_shard_count;
+    /* Form of the PRB adjoint (backward of the path integrator only).  ZDR_PRB_EXPECTATION (0, default): the derivative of
+     * the forward's expectation, which is what finite differences of render() measure (BASELINE.json's gradient bar) —
+     * Russian roulette without an upper clamp (prb.py:83) makes the expectation depend on the roulette probabilities and
+     * on the MIS weights, and this form differentiates through them.  ZDR_PRB_DETACHED (1): every roulette factor and MIS
+     * weight held constant, which is what the reference's autodiff blocks compute (prb.py:138-146, 157-163, with the
+     * corrected BSDF weight of SURVEY App. B-3). */
+    int32_t prb_mode;
 } zdr_render_params;
 
 typedef struct {

@@ -396,3 +396,29 @@ def test_few_texels_gradient_matches_oracle(tex, integrator, cbox_oracle):
     else:
         assert_grad_parity(got, ref, f"few texels {th}x{tw} {integrator}", n_paths=W * W * spp)
     assert abs(got.sum() - ref.sum()) <= 3e-4 * abs(ref.sum())
+
+
+@pytest.mark.parametrize("accel", ["brute", "bvh"])
+def test_detached_adjoint_mode_matches_oracle(accel, cbox_oracle, cbox_oracle_fma, mat_b):
+    """scene.prb_mode = "detached": the adjoint the reference's autodiff blocks compute — Russian-roulette factors and
+    MIS weights held constant (prb.py:138-146, 157-163) — against the oracle's ZDRO_PRB_DETACHED; it is NOT the default
+    because it is not the derivative finite differences measure (tests/test_oracle_render.py)."""
+    scene = make_scene("path", accel=accel)
+    scene.prb_mode = "detached"
+    W, spp, seed = 64, 16, 21
+    cot = np.random.default_rng(8).uniform(0.5, 1.5, (W, W, 4)).astype(np.float32)
+    m = torch.from_numpy(mat_b).cuda()
+    g = torch.zeros_like(m)
+    scene.render_backward(torch.from_numpy(cot).cuda(), g, m, (W, W), spp, seed)
+    p = oracle_params(scene, W, W, spp, seed + 1, mat_b.shape[:2], prb_mode=oracle.PRB_DETACHED)
+    ref = cbox_oracle.render_backward(p, cot, mat_b)
+    assert_grad_parity(g.cpu().numpy(), ref, f"detached adjoint / {accel}", floor=cbox_oracle_fma.render_backward(p, cot, mat_b), n_paths=W * W * spp)
+    scene.prb_mode = "expectation"
+    g2 = torch.zeros_like(m)
+    scene.render_backward(torch.from_numpy(cot).cuda(), g2, m, (W, W), spp, seed)
+    rough = (g2[..., 3] - g[..., 3]).abs().sum() / g2[..., 3].abs().sum()
+    assert rough > 0.01                                           # the roughness channel is where the two forms differ
+    from zdr_amd._native import ZdrError
+    scene.prb_mode = "literal"
+    with pytest.raises(KeyError):
+        scene.render_backward(torch.from_numpy(cot).cuda(), g2, m, (W, W), spp, seed)

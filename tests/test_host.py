@@ -24,7 +24,7 @@ def test_library_exports_every_symbol_of_the_header():
 
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_native.CameraPOD) == 40
-    assert C.sizeof(_native.RenderParams) == 4 * 15 + 40 + 8 + 8
+    assert C.sizeof(_native.RenderParams) == 4 * 15 + 40 + 8 + 12
     assert _native.RenderParams.camera.offset == 60 and _native.RenderParams.tex_h.offset == 100 and _native.RenderParams.tile_shard_count.offset == 112
     assert C.sizeof(_native.SceneInfo) == 48
 

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libzdr_hip.so")
 COLLOCATED, DIRECT, PATH, UVGRAD = 0, 1, 2, 3
 SAMPLER_CMJ, SAMPLER_PMJ02BN = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
+PRB_MODES = {"expectation": 0, "detached": 1}
 INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH}   # render.py:65-69
 SAMPLERS = {"cmj": SAMPLER_CMJ, "corrmj": SAMPLER_CMJ, "pmj02bn": SAMPLER_PMJ02BN}
 ACCELS = {"auto": ACCEL_AUTO, "brute": ACCEL_BRUTE, "bvh": ACCEL_BVH}
@@ -38,7 +39,7 @@ class RenderParams(C.Structure):
         ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
         ("max_depth", C.c_int32), ("rr_depth", C.c_int32),
         ("camera", CameraPOD), ("tex_h", C.c_int32), ("tex_w", C.c_int32),
-        ("tile_shard_index", C.c_int32), ("tile_shard_count", C.c_int32),
+        ("tile_shard_index", C.c_int32), ("tile_shard_count", C.c_int32), ("prb_mode", C.c_int32),
     ]
 
 

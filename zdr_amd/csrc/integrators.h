@@ -463,10 +463,11 @@ ZD int primary_pop(const DScene &S, const SamplerCfg &C, bool idle, const uint32
 //   e = {b = beta leaving (rr == 2) | (-1,0,0) (rr == 1) | 0, dln(pdf)/dr}
 struct PackedVertex { float4 a, b, c, d, e; };
 
-ZD PackedVertex pack_vertex(const PathVertex &v, f3 g) {
+// detached (ZDR_PRB_DETACHED): the MIS weights and the Russian-roulette factors are constants — no neeM, no RR fields, no score
+ZD PackedVertex pack_vertex(const PathVertex &v, f3 g, bool detached = false) {
     PackedVertex p;
     p.a = brdf_grad(v.cL, v.dfLdr, v.bW * g);
-    p.a.w -= dot(g, v.neeM);
+    if (!detached) p.a.w -= dot(g, v.neeM);
     f3 Q = v.bpq * v.c;
     float r = (v.c > 0.0f) ? v.dfdr * rcp(v.c) : 0.0f;
     p.b = make_float4(Q.x, Q.y, Q.z, r);
@@ -474,7 +475,7 @@ ZD PackedVertex pack_vertex(const PathVertex &v, f3 g) {
     f3 gA = g * v.fLW;
     p.d = make_float4(gA.x, gA.y, gA.z, v.uv.y);
     f3 e = (v.rr == 2) ? v.bnorm : ((v.rr == 1) ? mk3(-1.0f, 0.0f, 0.0f) : mk3(0.0f));
-    p.e = make_float4(e.x, e.y, e.z, v.dlnp);
+    p.e = detached ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(e.x, e.y, e.z, v.dlnp);
     return p;
 }
 

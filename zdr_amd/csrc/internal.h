@@ -27,6 +27,7 @@ struct RenderCfg {
     int32_t shard_index, shard_count, ntiles;   // interleaved tile shard: tiles index, index + count, ... ; ntiles = how many that is
     int32_t use_tent, max_depth, rr_depth;
     int32_t tex_h, tex_w;
+    int32_t prb_detached;             // backward, path: roulette factors and MIS weights held constant (zdr.h, ZDR_PRB_DETACHED)
     int32_t cell_copies;              // backward: replicas of the staging-cell array (scene.h: few texels), >= 1
     float two_over_w, two_over_h, aspect;      // integrator.py:22-23
     float inv_spp;                             // 1 / spp as computed by IEEE division

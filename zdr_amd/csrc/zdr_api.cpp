@@ -646,6 +646,8 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     // 256 CUs x 4 SIMDs busy with several waves each and to let the dispatcher balance uneven tiles
     R.tiles_x = (p->x1 - p->x0 + 7) / 8; R.tiles_y = (p->y1 - p->y0 + 7) / 8;
     uint32_t ns = p->sample_end - p->sample_begin;
+    if (p->prb_mode != ZDR_PRB_EXPECTATION && p->prb_mode != ZDR_PRB_DETACHED) return fail(ZDR_E_INVALID, "unknown prb_mode");
+    R.prb_detached = p->prb_mode == ZDR_PRB_DETACHED;
     R.shard_count = p->tile_shard_count > 1 ? p->tile_shard_count : 1;
     R.shard_index = p->tile_shard_count > 1 ? p->tile_shard_index : 0;
     const long all_tiles = (long)R.tiles_x * R.tiles_y;

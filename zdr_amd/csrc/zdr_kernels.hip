@@ -350,7 +350,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
                 PathVertex pv; float term_plfrac = 0.0f;
                 Hit h;
                 done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
-                plast = pack_vertex(pv, le_grad);
+                plast = pack_vertex(pv, le_grad, R.prb_detached != 0);
                 if (nrec < lds_vertices) plast.e = make_float4(0.0f, 0.0f, 0.0f, plast.e.w);   // LDS records carry no RR fields
                 if (!done) { path_continue<A, false>(S, lds, ps, h, cnt); done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac); }
                 // Only a vertex whose path goes on is put away: when the path ends here (52 % of the vertices) the sweep below starts
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
                     if (!any_nan(ps.L) && nrec > 0) {       // prb.py:100: NaN paths contribute nothing
                         sw_k = (R.debug_no_scatter == 3) ? -1 : nrec - 1;   // ablation 3: no sweep at all
                         sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f;
-                        sw.tw = term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
+                        sw.tw = R.prb_detached ? 0.0f : term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
                     }
                 }
             }
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, Sampl
         const int slot = h.slot;
         term_Li = mk3(0.0f); plfrac = 0.0f;
         bool stop = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h2, cnt);
-        recs[nv] = pack_vertex(pv, le_grad);
+        recs[nv] = pack_vertex(pv, le_grad, R.prb_detached != 0);
         if (nv < maxv) {
             float *q = o + 8 + 24 * nv;
             const int went_on = pv.c != 0.0f ? 1 : 0;       // the BSDF sample was kept (prb.py:73-87 passed)
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, Sampl
     }
     o[0] = __int_as_float(nv); o[1] = ps.L.x; o[2] = ps.L.y; o[3] = ps.L.z; o[5] = term_Li.x; o[6] = term_Li.y; o[7] = term_Li.z;
     if (!any_nan(ps.L) && nv > 0) {                         // prb.py:100; the sweep of k_path_bwd
-        SweepState sw; sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f; sw.tw = plfrac * dot(ps.beta, sw.A);
+        SweepState sw; sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f; sw.tw = R.prb_detached ? 0.0f : plfrac * dot(ps.beta, sw.A);
         for (int k = nv - 1; k >= 0; k--) {
             f2 guv; const float4 g = sweep_vertex(recs[k], sw, guv);
             if (k < maxv) { float *q = o + 8 + 24 * k; q[12] = g.x; q[13] = g.y; q[14] = g.z; q[15] = g.w; }

@@ -53,6 +53,7 @@ class Scene:
         self.sampler = sampler
         self.max_depth = MAX_DEPTH
         self.rr_depth = RR_DEPTH
+        self.prb_mode = "expectation"      # or "detached": the reference's constant-roulette / constant-MIS adjoint (include/zdr.h)
         self.env_count = 0
         self._handle = None
         self.load_geometry(models, accel=accel)
@@ -138,6 +139,7 @@ class Scene:
         p.camera = _camera_pod(camera if camera is not None else self.camera)
         p.tex_h, p.tex_w = int(tex_hw[0]), int(tex_hw[1])
         p.tile_shard_index, p.tile_shard_count = tile_shard if tile_shard is not None else (0, 1)
+        p.prb_mode = N.PRB_MODES[self.prb_mode]
         return p
 
     def _check_material(self, material):

@@ -16,6 +16,16 @@ import numpy as np
 SAMPLE_MAP_W, SAMPLE_MAP_H = 512, 256          # envmap.py:114
 
 
+def load_image(path: str) -> np.ndarray:
+    """envmap.py:117-121 reads the file with imageio; here: OpenEXR (zdr_amd/exr.py) or a .npy array."""
+    if path.lower().endswith(".exr"):
+        from .exr import read_exr
+        return read_exr(path)
+    if path.lower().endswith(".npy"):
+        return np.load(path)
+    raise NotImplementedError(f"{path}: environment maps are read from .exr or .npy files (or passed as arrays)")
+
+
 def prepare_image(img) -> np.ndarray:
     """(H, W, 3|4) -> float32 RGBA, made square like load_envmap (envmap.py:122-128, render.py:151-154)."""
     img = np.asarray(img, np.float32)

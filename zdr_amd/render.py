@@ -91,17 +91,16 @@ class Scene:
 
     def add_envmap(self, image, compensate_mis=True):
         """Adds a lat-long environment light (render.py:150-156, envmap.py:116-203).  ``image`` is an
-        (H, W, 3|4) float array / tensor (2:1 or 1:1) or the path of a ``.npy`` file holding one — the
-        reference reads an EXR through imageio, which this image does not ship.  ``None`` removes it."""
+        (H, W, 3|4) float array / tensor (2:1 or 1:1) or the path of an OpenEXR file (the reference reads it
+        through imageio; here zdr_amd/exr.py: scan-line files, NONE / ZIPS / ZIP compression) or of a ``.npy``
+        file.  ``None`` removes it."""
         from . import envmap as E
         if image is None:
             N.check(N.lib().zdr_scene_set_envmap(self._handle, None, 0, 0, None, None, None, 0, 0))
             self.env_count = 0
             return
         if isinstance(image, str):
-            if not image.endswith(".npy"):
-                raise NotImplementedError("only .npy environment maps can be read here (no EXR reader in this environment); pass an array instead")
-            image = np.load(image)
+            image = E.load_image(image)               # .exr (zdr_amd/exr.py) or .npy
         if isinstance(image, torch.Tensor):
             image = image.detach().cpu().numpy()
         img = E.prepare_image(image)

@@ -73,7 +73,7 @@ typedef struct {
 typedef struct {
     uint32_t ntris, nverts, ninst, light_count;
     int32_t accel;                     /* ZDR_ACCEL_BRUTE or ZDR_ACCEL_BVH actually in use */
-    uint32_t bvh_nodes, bvh_max_depth, bvh_stack_entries;   /* BVH4 nodes, depth of the binary SAH tree, traversal-stack entries per lane the tree can need (8 in LDS, the rest in scratch) */
+    uint32_t bvh_nodes, bvh_max_depth, bvh_stack_entries;   /* BVH4 nodes, depth of the binary SAH tree, traversal-stack entries per lane the tree can need (the first 6-12 in LDS, the rest in scratch) */
     int32_t device;
     uint64_t device_bytes;             /* HBM held by the scene */
 } zdr_scene_info_t;

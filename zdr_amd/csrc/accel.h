@@ -297,8 +297,8 @@ struct BvhAccel {
         hit.slot = -1; hit.u = 0.0f; hit.v = 0.0f; hit.t = tmaxB;
         if (!(HAS_A && needA) && !needB) return;
         bool first = HAS_A && needA;                         // this lane is still on its any-hit ray
-        const int LN = (S.stack_entries < ZDR_BVH_LDS_STACK) ? S.stack_entries : ZDR_BVH_LDS_STACK;
-        int deep[ZDR_BVH_STACK - ZDR_BVH_LDS_STACK + 4];
+        const int LN = S.lds_stack;
+        int deep[ZDR_BVH_STACK];
         Walker w;
         if (first) start(S, w, oA, dA, tminA, tmaxA); else start(S, w, oB, dB, tminB, tmaxB);
         for (;;) {

@@ -5,8 +5,14 @@
 #include "vecmath.h"
 
 #define ZDR_BVH_STACK 64   // upper bound of per-lane traversal stack entries; the builder bounds the tree depth below it
+// of which this many live in LDS (the rest, rarely reached, in scratch), per kind of kernel: the backward kernel's waves per CU are
+// decided by LDS, the forward kernel's by VGPRs.  1 M triangles, 1024^2 spp 32, ms with 6 / 8 / 12 / 16 entries in LDS: forward
+// 32.9 / 31.8 / 31.4 / 31.3, backward 39.9 / 41.5 / 40.8 / 44.1.
 #ifndef ZDR_BVH_LDS_STACK
-#define ZDR_BVH_LDS_STACK 8    // of which this many live in LDS (the rest, rarely reached, in scratch); 1 M triangles, fwd / bwd ms: 44 (all) 94 / 149, 16: 92 / 115, 12: 91 / 115, 8: 93 / 108
+#define ZDR_BVH_LDS_STACK 12
+#endif
+#ifndef ZDR_BVH_LDS_STACK_BWD
+#define ZDR_BVH_LDS_STACK_BWD 6
 #endif
 
 // Per-slot records, 16-byte aligned so a record is fetched with dwordx4 loads:
@@ -37,7 +43,8 @@ struct DScene {
     // environment light (envmap.py; heap slots 23330-23332): lat-long RGBA texture + importance tables
     const float4 *env_tex; const float *alias_prob; const int32_t *alias_idx; const float *env_pdf;
     int32_t env_count, env_h, env_w, map_w, map_h;
-    int32_t stack_entries;          // per-lane traversal stack entries this tree needs (dynamic LDS: min(entries, ZDR_BVH_LDS_STACK) x 64 ints per wave)
+    int32_t stack_entries;          // per-lane traversal stack entries this tree needs
+    int32_t lds_stack;              // how many of them this launch keeps in LDS (dynamic LDS: lds_stack x 64 ints per wave), set by the launcher
     // Device error word (sticky until the host reads it: zdr_scene_check, zdr_render_stats, ZDR_CHECK=1).  A watchdog
     // that ends work early ORs its bit in, so an incomplete image or gradient can never pass as a good one.
     unsigned int *error_word;

@@ -523,8 +523,11 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 }
 
 // ----------------------------------------------------------------------------------- launch
-// dynamic LDS of a wave that traverses the BVH: the first entries of the per-lane stacks (accel.h)
-static size_t bvh_dyn_lds(const DScene &S) { return (size_t)std::min<int>(S.stack_entries, ZDR_BVH_LDS_STACK) * WAVE * sizeof(int); }
+// dynamic LDS of a wave that traverses the BVH: the first entries of the per-lane stacks (accel.h).  Sets S.lds_stack.
+static size_t bvh_dyn_lds(DScene &S, bool backward) {
+    S.lds_stack = std::min<int>(S.stack_entries, backward ? ZDR_BVH_LDS_STACK_BWD : ZDR_BVH_LDS_STACK);
+    return (size_t)S.lds_stack * WAVE * sizeof(int);
+}
 // Persistent grid of the path kernels: as many single-wave workgroups as the chip holds at once (never more
 // than there are items).  A workgroup that is not resident at first simply starts later and draws what is left.
 template <class K>
@@ -585,12 +588,13 @@ static void launch_integ(int integrator, dim3 grid, size_t dyn, hipStream_t st, 
     else launch_simple<ZDR_COLLOCATED, SK, A>(grid, dyn, st, S, R, C, io, backward, stats);
 }
 
-int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
+int zdr_launch_render(const DScene &S_in, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
                       int integrator, int accel_is_bvh, int backward, int stats, hipStream_t st) {
+    DScene S = S_in;
     int nblocks = R.ntiles * R.nchunks;
     if (nblocks <= 0) return 0;
     dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
-    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S) : 0;
+    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S, backward != 0) : 0;
     if (io.tile_masks && !io.tile_masks_valid)
         hipLaunchKernelGGL(k_tile_masks, dim3(R.tiles_x * R.tiles_y), dim3(WAVE), 0, st, S, R, (unsigned long long *)io.tile_masks);
     if (C.kind == ZDR_SAMPLER_CMJ) {
@@ -632,12 +636,13 @@ __global__ __launch_bounds__(WAVE) void k_trace(DScene S, const float4 *rays, ui
     }
 }
 
-int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *rays, uint32_t n, int32_t *out_i, float *out_f, hipStream_t st) {
+int zdr_launch_trace(const DScene &S_in, int accel_is_bvh, int any, const float *rays, uint32_t n, int32_t *out_i, float *out_f, hipStream_t st) {
+    DScene S = S_in;
     if (n == 0) return 0;
     dim3 grid((n + WAVE - 1) / WAVE);
     const float4 *r = (const float4 *)rays;
     if (accel_is_bvh) {
-        const size_t dyn = bvh_dyn_lds(S);
+        const size_t dyn = bvh_dyn_lds(S, false);
         if (any) hipLaunchKernelGGL((k_trace<BvhAccel, true>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
         else hipLaunchKernelGGL((k_trace<BvhAccel, false>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
     } else {
@@ -709,11 +714,12 @@ __global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, Sampl
     }
 }
 
-int zdr_launch_path_dump(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int accel_is_bvh,
+int zdr_launch_path_dump(const DScene &S_in, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int accel_is_bvh,
                          const int32_t *queries, uint32_t n, int32_t maxv, float *out, hipStream_t st) {
+    DScene S = S_in;
     if (n == 0) return 0;
     dim3 grid((n + WAVE - 1) / WAVE);
-    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S) : 0;
+    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S, true) : 0;
 #define ZDR_DUMP(SKV, ACC, ENVV) hipLaunchKernelGGL((k_path_dump<SKV, ACC, ENVV>), grid, dim3(WAVE), dyn, st, S, R, C, io, queries, n, maxv, out)
     const bool env = S.env_count > 0, cmj = C.kind == ZDR_SAMPLER_CMJ;
     if (accel_is_bvh) { if (cmj) { if (env) ZDR_DUMP(0, BvhAccel, true); else ZDR_DUMP(0, BvhAccel, false); } else { if (env) ZDR_DUMP(1, BvhAccel, true); else ZDR_DUMP(1, BvhAccel, false); } }

@@ -13,7 +13,7 @@
 #define ZDR_MIN_WAVES 3
 #endif
 #ifndef ZDR_MIN_WAVES_BVH
-#define ZDR_MIN_WAVES_BVH 5
+#define ZDR_MIN_WAVES_BVH 6    // 1 M triangles, forward ms at 1024^2 spp 32 with 4 / 5 / 6 / 7 / 8 waves per SIMD: 32.8 / 31.4 / 30.3 / 31.4 / 39.4
 #endif
 #ifndef ZDR_MIN_WAVES_BWD
 #define ZDR_MIN_WAVES_BWD ZDR_MIN_WAVES
@@ -172,7 +172,7 @@ ZD float qbox_entry(uint32_t nxq, uint32_t nyq, uint32_t nzq, uint32_t fxq, uint
 
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
-    static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // latency-bound: 5 waves per SIMD (<= 102 VGPRs, a few spills) is 15 % faster than 3 on 1 M triangles
+    static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // 6 waves per SIMD (<= 80 VGPRs: the path state that is cold during the walk is spilled around it); sweep at ZDR_MIN_WAVES_BVH
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES_BVH;    // <= 128 VGPRs give 15 waves per CU instead of 11 (109 -> 94 ms on 1 M triangles)
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }

@@ -86,12 +86,12 @@ def test_light_sampling_and_bsdf_sampling_agree_under_a_sun(sky_tables):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("integrator", ["direct", "path"])
-def test_hip_environment_lighting_matches_oracle(integrator, cbox_arrays, sky_tables):
+@pytest.mark.parametrize("integrator,accel", [("direct", "brute"), ("path", "brute"), ("path", "bvh"), ("direct", "bvh")])
+def test_hip_environment_lighting_matches_oracle(integrator, accel, cbox_arrays, sky_tables):
     import torch
     from gpu_util import assert_grad_parity, assert_image_parity, make_scene, oracle_params
     I, prob, alias, pdf = sky_tables
-    scene = make_scene(integrator)
+    scene = make_scene(integrator, accel=accel)
     scene.add_envmap(sun_sky())
     assert scene.env_count == 1 and np.array_equal(scene._envmap[1], prob)
     S = oracle.OracleScene.from_arrays(cbox_arrays); Sf = oracle.OracleScene.from_arrays(cbox_arrays, variant="fma")
@@ -109,7 +109,7 @@ def test_hip_environment_lighting_matches_oracle(integrator, cbox_arrays, sky_ta
     assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, ones, mat), f"envmap {integrator} backward", floor=Sf.render_backward(pb, ones, mat))
     # removing the environment restores the plain scene
     scene.add_envmap(None)
-    plain = make_scene(integrator).render(m.detach(), res=(32, 32), spp=4)
+    plain = make_scene(integrator, accel=accel).render(m.detach(), res=(32, 32), spp=4)
     assert torch.equal(scene.render(m.detach(), res=(32, 32), spp=4), plain)
 
 

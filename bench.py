@@ -206,7 +206,7 @@ def main():
     bwd_ms = sum(a.elapsed_time(b) for a, b in ev["bwd"]) / max(args.steps, 1)
 
     if rank == 0:
-        shard = renderer and zd.plan(args.shard, 0, world, (W, W), spp, 0)
+        shard = zd.plan(args.shard, 0, world, (W, W), spp, 0)
         stats = {}
         for rect in shard.rects:                            # path statistics of rank 0's share of one pass
             for k, v in scene.render_stats(material.detach(), (W, W), spp, seed=0, rect=rect, samples=shard.samples, tile_shard=shard.tile_shard).items():

@@ -73,37 +73,6 @@ def scatter_gradients(tr, tex_h, tex_w):
     return out
 
 
-def compare(got, ref, rel=1e-4, what=""):
-    """Float fields of the paths whose signatures agree.  Returns (n_same, n_flipped, worst relative deviations)."""
-    same = got.signature_equal(ref)
-    live = got.live & same[:, None]
-    has_bsdf = live & ((got.flags & 2) != 0)
-    dev = {}
-
-    def rel_dev(a, b, mask, scale=None):
-        a = a[mask].astype(np.float64); b = b[mask].astype(np.float64)
-        if a.size == 0:
-            return 0.0, np.zeros(0)
-        s = np.abs(b) if scale is None else scale
-        d = np.abs(a - b) / np.maximum(s, 1e-30)
-        return float(d.max()), d
-
-    # per-vertex quantities, each relative to the vertex's own magnitude
-    dev["uv"] = rel_dev(got.uv, ref.uv, live, scale=1.0)[0]
-    dev["pdf"] = rel_dev(got.pdf, ref.pdf, has_bsdf)[0]
-    dev["wi"] = rel_dev(got.wi, ref.wi, has_bsdf, scale=1.0)[0]
-    nb = np.linalg.norm(ref.beta_out.astype(np.float64), axis=2, keepdims=True)
-    dev["beta_out"] = rel_dev(got.beta_out, ref.beta_out, has_bsdf, scale=np.broadcast_to(nb, ref.beta_out.shape)[has_bsdf])[0]
-    # radiance and gradients relative to the path's own radiance / gradient magnitude
-    nl = np.maximum(np.linalg.norm(ref.L.astype(np.float64), axis=1, keepdims=True), 1e-20)
-    finite = same & ~np.isnan(ref.L).any(axis=1) & ~np.isnan(got.L).any(axis=1)
-    dev["L"] = rel_dev(got.L, ref.L, finite, scale=np.broadcast_to(nl, ref.L.shape)[finite])[0]
-    ng = np.maximum(np.abs(ref.grad.astype(np.float64)).max(axis=(1, 2), keepdims=True), 1e-30)
-    gl = live & finite[:, None]
-    dev["grad"] = rel_dev(got.grad, ref.grad, gl, scale=np.broadcast_to(ng, ref.grad.shape)[gl])[0]
-    return int(same.sum()), int((~same).sum()), dev
-
-
 def deviation_percentiles(got, ref, pct=(50, 90, 99, 100)):
     """Per path, over the paths whose signatures agree: the largest deviation of the radiance (relative to the path's own
     radiance) and of the vertex gradients (relative to the path's largest gradient component)."""

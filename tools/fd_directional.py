@@ -17,10 +17,16 @@ ap.add_argument("--seeds", type=int, default=32)
 ap.add_argument("--rr-depth", type=int, default=2)
 ap.add_argument("--max-depth", type=int, default=16)
 ap.add_argument("--eps", type=float, default=0.01)
+ap.add_argument("--scene", default="cbox", choices=["cbox", "tess1m"], help="tess1m: the 1,004,672-triangle tessellated cbox (BASELINE configs[4], BVH kernels)")
 ap.add_argument("--only", default="", help="comma list of diffuse,roughness,all")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fd_directional.json"))
 a = ap.parse_args()
-scene = make_scene("path")
+if a.scene == "tess1m":
+    from conftest import cbox_models
+    from zdr_amd import procedural
+    scene = make_scene("path", arrays=procedural.tessellated_cbox(cbox_models(), n=183))
+else:
+    scene = make_scene("path")
 scene.rr_depth, scene.max_depth = a.rr_depth, a.max_depth
 W = a.res
 material = torch.from_numpy(fd_material_np(1024, 0)).cuda()
@@ -45,4 +51,4 @@ for name, chans in (("diffuse", slice(0, 3)), ("roughness", slice(3, 4)), ("all"
     sig = np.hypot(ad.std(ddof=1), fd.std(ddof=1)) / np.sqrt(a.seeds) / abs(fd.mean())
     res[name] = {"AD": ad.mean(), "AD_se": ad.std(ddof=1) / np.sqrt(a.seeds), "FD": fd.mean(), "FD_se": fd.std(ddof=1) / np.sqrt(a.seeds), "rel_err": rel, "one_sigma": sig}
     print(f"{name:9s}: AD = {ad.mean():.4f} +- {res[name]['AD_se']:.4f}  FD = {fd.mean():.4f} +- {res[name]['FD_se']:.4f}  rel-err {rel:.2e} (1 sigma {sig:.2e})", flush=True)
-json.dump({"res": W, "spp": a.spp, "seeds": a.seeds, "fd_eps": a.eps, "result": res}, open(a.out, "w"), indent=1)
+json.dump({"scene": a.scene, "res": W, "spp": a.spp, "seeds": a.seeds, "fd_eps": a.eps, "result": res}, open(a.out, "w"), indent=1)

@@ -7,8 +7,10 @@ ROCm).  Payloads are small (16 MiB each at 1024^2), far below what the render it
 
 Shard modes
   "tiles"    pixel tiles: the 8x8 tiles of the image dealt round-robin to the ranks, ONE launch per rank
-             (zdr_render_params.tile_shard_*); union is bit-identical to the unsharded image.  BASELINE configs[3].
-  "rows"     pixel tiles: interleaved bands of rows (one launch per band); union bit-identical as well
+             (zdr_render_params.tile_shard_*); every pixel receives the same samples whoever renders it: the union equals the
+             unsharded image bit for bit when both cut the sample range into the same chunks, otherwise up to float
+             re-association of the per-pixel sum.  BASELINE configs[3].
+  "rows"     pixel tiles: interleaved bands of rows (one launch per band); same samples per pixel as well
   "samples"  sample-index ranges [k*spp/N, (k+1)*spp/N) of the same sample set
   "seeds"    every rank renders the whole image with its own seed (seed + rank * SEED_STRIDE); the
              mean over ranks is an N*spp-sample estimate (weak scaling: fixed work per GPU)

@@ -655,7 +655,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     long tiles = R.ntiles;
     long target_waves = 65536;            // work items (tile x sample chunk) the persistent waves draw; cbox 512^2 spp 256: 16384 11.3/18.5 ms, 32768 10.7/17.7, 65536 10.25/17.2, 131072 10.2/17.1
     if (const char *e = getenv("ZDR_TARGET_WAVES")) target_waves = std::max(1L, atol(e));
-    uint32_t min_chunk = 16;
+    uint32_t min_chunk = 8;               // = one refill batch; cbox 512^2 forward / backward ms with 16 / 8 / 4: spp 16 1.10 / 0.99 / 1.06, 1.63 / 1.41 / 1.41; spp 64 2.90 / 2.86 / 2.92, 4.35 / 4.12 / 4.16; spp 256 unchanged
     if (const char *e = getenv("ZDR_MIN_CHUNK")) min_chunk = (uint32_t)std::max(1L, atol(e));
     long want = tiles > 0 ? (target_waves + tiles - 1) / tiles : 1;
     long maxc = std::max<long>(1, ns / min_chunk);

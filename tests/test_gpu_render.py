@@ -155,6 +155,27 @@ def test_interleaved_tile_shards_union(integrator, accel, count, mat_a):
     assert stats == scene.render_stats(m, (W, H), spp, 6)
 
 
+def test_tile_shards_inside_a_rectangle_and_for_uvgrad(mat_a):
+    """Tile shards are numbered from the rectangle's own corner, so they compose with rectangle shards; and the
+    render_duvdxy kernel (which writes the image directly, one chunk) honours them too."""
+    scene = make_scene("path")
+    m = torch.from_numpy(mat_a).cuda()
+    W, H, spp = 61, 45, 16
+    rect = (13, 7, 58, 41)
+    whole = scene.render_forward(m, (W, H), spp, 3, rect=rect, out=torch.full((H, W, 4), -1.0, device="cuda"))
+    parts = torch.full_like(whole, -1.0)
+    for r in range(3):
+        scene.render_forward(m, (W, H), spp, 3, rect=rect, tile_shard=(r, 3), out=parts)
+    assert torch.equal(parts, whole)
+    assert (whole[:7] == -1).all() and (whole[:, :13] == -1).all() and (whole[41:] == -1).all() and (whole[:, 58:] == -1).all()
+    from zdr_amd import _native as N
+    uv = scene.render_forward(m, (W, H), spp, 3, kernel=N.UVGRAD)
+    uparts = torch.zeros_like(uv)
+    for r in range(4):
+        scene.render_forward(m, (W, H), spp, 3, kernel=N.UVGRAD, tile_shard=(r, 4), out=uparts)
+    assert torch.equal(uparts, uv)
+
+
 @pytest.mark.parametrize("integrator", ["collocated", "direct", "path"])
 def test_tile_masks_cull_nothing_that_can_be_hit(integrator, mat_a, monkeypatch):
     """Camera rays of a tile test only the triangle pairs in the tile's mask (k_tile_masks).  The mask may keep

@@ -44,7 +44,8 @@ def test_void_and_cluster_is_blue_noise():
 
 
 @pytest.mark.gpu
-def test_pmj02bn_render_with_generated_tables_matches_oracle_and_cmj(cbox_arrays):
+@pytest.mark.parametrize("accel", ["brute", "bvh"])
+def test_pmj02bn_render_with_generated_tables_matches_oracle_and_cmj(accel, cbox_arrays):
     import ctypes as C
     import torch
     import oracle
@@ -52,7 +53,7 @@ def test_pmj02bn_render_with_generated_tables_matches_oracle_and_cmj(cbox_arrays
     from gpu_util import assert_image_parity, make_scene, oracle_params
     pmj = T.pmj02_sets(n_sets=5, n_samples=1024, seed=0)
     bn = T.blue_noise_textures(n_tex=4, res=32, seed=0)
-    scene = make_scene("path")
+    scene = make_scene("path", accel=accel)
     scene.sampler = "pmj02bn"
     scene.set_pmj02bn_tables(pmj, bn)
     mat = cbox_material_np()

@@ -445,3 +445,37 @@ def test_detached_adjoint_mode_matches_oracle(accel, cbox_oracle, cbox_oracle_fm
     scene.prb_mode = "literal"
     with pytest.raises(KeyError):
         scene.render_backward(torch.from_numpy(cot).cuda(), g2, m, (W, W), spp, seed)
+
+
+def test_rccl_single_rank_exchange(mat_a):
+    """The exchange step of the multi-GPU path (zdr_amd/distributed.py: one all_reduce of the image and one of the
+    gradient) on the RCCL backend with the ranks this box has: ONE.  Not a scaling test — it shows that torch.distributed's
+    "nccl" backend (= RCCL on ROCm) initialises on the MI355X box and reduces the tensors the renderer hands it."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from zdr_amd import distributed as zd
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        scene = make_scene("path")
+        m = torch.from_numpy(mat_a).cuda().requires_grad_()
+        r = zd.attach(scene, mode="tiles")
+        img = r.render(m, res=(64, 64), spp=16, seed=1)
+        ref = scene.render_forward(m.detach(), (64, 64), 16, 1)
+        assert torch.equal(img, ref)
+        t = img.detach().clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                 # the collective the N-rank run issues, on RCCL
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref)
+        img.sum().backward()
+        g = m.grad.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert torch.equal(g, m.grad) and float(g.abs().sum()) > 0
+    finally:
+        dist.destroy_process_group()

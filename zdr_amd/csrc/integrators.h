@@ -240,119 +240,146 @@ ZD bool path_arrive(const DScene &S, PathState &ps, const Hit &h, Interaction &i
 //                        continuation ray as soon as its shadow ray has ended; no shadow ray at all when the light
 //                        sample carries nothing), then the NEE terms are added if the shadow ray came through.
 // BWD: fills pv, the record of this vertex.
-template <int SK, class A, bool BWD, bool STATS, bool ENV>
-ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
-                   PathState &ps, const Interaction &it, PathVertex &pv, Hit &h, Counters &cnt) {
+struct ShadeCtx { f3 diffuse; float roughness; Onb onb; f3 wo, wil; LightSample light; };
+// The light sample's contribution AS IF it were unoccluded (prb.py:60-66); applied once the shadow ray is known to be free.
+struct NeeTerms { f3 dL, bW, fLW, neeM; float cL, dfLdr; };
+
+// material, frame and the light sample of the vertex (prb.py:47-58); BWD: resets pv
+template <int SK, bool BWD, bool STATS, bool ENV>
+ZD ShadeCtx shade_ctx(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, PathState &ps, const Interaction &it, PathVertex &pv, Counters &cnt) {
+    ShadeCtx x;
     float4 m = read_bsdf(io.material, it.uv, R.tex_h, R.tex_w);
-    f3 diffuse = mk3(m.x, m.y, m.z); float roughness = m.w;
+    x.diffuse = mk3(m.x, m.y, m.z); x.roughness = m.w;
     COUNT(C_SHADED);
     if (BWD) {
         pv.uv = it.uv; pv.bW = mk3(0.0f); pv.cL = 0.0f; pv.dfLdr = 0.0f; pv.bpq = mk3(0.0f); pv.c = 0.0f; pv.dfdr = 0.0f;
         pv.T = mk3(0.0f); pv.fLW = mk3(0.0f); pv.bnorm = mk3(0.0f); pv.neeM = mk3(0.0f); pv.dlnp = 0.0f; pv.rr = 0;
     }
-    Onb onb = make_onb(it.ns);
-    f3 wo = to_local(onb, -ps.d);
+    x.onb = make_onb(it.ns);
+    x.wo = to_local(x.onb, -ps.d);
     // next-event estimation: the light sample (prb.py:57-58)
     float u_pick = sampler_next<SK>(C, ps.smp);
-    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
-    const f3 wil = to_local(onb, light.wi);
+    x.light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
+    x.wil = to_local(x.onb, x.light.wi);
+    return x;
+}
 
-    // The light sample's contribution AS IF it were unoccluded (prb.py:60-66); applied once the shadow ray is known to be free.
-    struct NeeTerms { f3 dL, bW, fLW, neeM; float cL, dfLdr; };
-    auto nee_terms = [&](f3 beta_in) {                                            // beta_in: throughput arriving at the vertex
-        NeeTerms n; n.dL = n.bW = n.fLW = n.neeM = mk3(0.0f); n.cL = 0.0f; n.dfLdr = 0.0f;
-        GgxTerms g = ggx_terms(wo, wil, roughness);
-        f3 bsdf = ggx_brdf_from(g, wil, diffuse);
-        float pb = ggx_pdf_from(g, wo, wil);
-        float mis = balanced_heuristic(light.pdf, pb);
-        float inv_dn = rcp(fmaxf(light.pdf, 1e-4f));
-        n.dL = (((beta_in * bsdf) * mis) * light.eval) * inv_dn;
-        if (BWD) {
-            f3 W = (light.eval * mis) * inv_dn;
-            float dlnpL;
-            n.bW = beta_in * W; n.cL = wil.z * ZDR_INV_PI; n.dfLdr = ggx_dfdr_from(g, wo, wil, roughness, dlnpL);
-            n.fLW = bsdf * W;
-            float pbf = (light.pdf + pb > 1e-4f) ? pb * rcp(light.pdf + pb) : 0.0f;   // d w_nee/dr = -w_nee pb/(pl+pb) dln(pb)/dr
-            n.neeM = ((beta_in * bsdf) * W) * (pbf * dlnpL);
-        }
-        return n;
-    };
-    auto nee_apply = [&](const NeeTerms &n) {
-        ps.L = ps.L + n.dL;
-        if (BWD) { pv.bW = n.bW; pv.cL = n.cL; pv.dfLdr = n.dfLdr; pv.fLW = n.fLW; pv.neeM = n.neeM; }
-    };
-    auto sample_bsdf = [&]() -> bool {                                            // prb.py:69-87; true = the path stops here
-        float u_lobe = sampler_next<SK>(C, ps.smp);
-        f2 u_dir = sampler_next2<SK>(C, ps.smp);
-        f3 wi_local = ggx_sample(wo, roughness, u_lobe, u_dir);
-        GgxTerms g = ggx_terms(wo, wi_local, roughness);
-        ps.pdf_bsdf = ggx_pdf_from(g, wo, wi_local);
-        f3 wi = to_world(onb, wi_local);
-        bool stop = (dot(wi, it.ng) < 1e-4f) || (wi_local.z < 1e-4f);             // prb.py:73-74
-        const f3 beta_in = ps.beta;
-        float q = 1.0f;
-        int rr_kind = 0;
-        if (!stop) {
-            ps.o = offset_ray_origin(it.p, it.ng); ps.d = wi;
-            f3 f = ggx_brdf_from(g, wi_local, diffuse);
-            float inv_p = rcp(ps.pdf_bsdf);
-            ps.beta = ps.beta * (f * inv_p);
-            if (ps.depth >= R.rr_depth) {                                         // prb.py:79-87
-                float l = 0.212671f * ps.beta.x + 0.715160f * ps.beta.y + 0.072169f * ps.beta.z;
-                if (l == 0.0f) stop = true;
-                else {
-                    q = fmaxf(l, 0.05f);
-                    float r = sampler_next<SK>(C, ps.smp);
-                    if (r >= q) stop = true;
-                    else { ps.beta = ps.beta * rcp(q); rr_kind = (l >= 1.0f) ? 2 : ((l >= 0.05f) ? 1 : 0); }
-                }
-            }
-            if (BWD && !stop) {
-                float inv_pq = inv_p * rcp(q);
-                pv.bpq = beta_in * inv_pq; pv.c = wi_local.z * ZDR_INV_PI; pv.dfdr = ggx_dfdr_from(g, wo, wi_local, roughness, pv.dlnp);
-                pv.T = f * inv_pq;
-                // prb.py:83 has no upper clamp on q: for lum(beta') >= 1 the path survives with certainty and is
-                // STILL divided by q = lum(beta'), i.e. beta leaves this vertex with unit luminance.  The forward's
-                // expectation then depends on q(material); the sweep differentiates through it (sweep_vertex).
-                pv.rr = rr_kind;
-                if (rr_kind == 2) pv.bnorm = ps.beta;
-            }
-        }
-        ps.depth++;
-        if (ps.depth >= R.max_depth) stop = true;
-        return stop;
-    };
-
-    COUNT(C_SHADOW);
-    bool stop;
-    if constexpr (A::kFuseRays) {
-        // The NEE arithmetic comes first, so that only its results (not the frame, the light sample and the material) have
-        // to live through the traversal — and so that the shadow ray can be SKIPPED when nothing rides on it: a light
-        // sample below the horizon (prb.py:62) or one that carries exactly nothing even if visible (a light seen from
-        // behind or edge-on has eval = 0, light.py:76).  On the Cornell box that is every vertex of the ceiling.  Exact:
-        // only all-zero, NaN-free terms are dropped, so the image and the gradients are the reference's bit for bit.
-        NeeTerms n; n.dL = n.bW = n.fLW = n.neeM = mk3(0.0f); n.cL = 0.0f; n.dfLdr = 0.0f;
-        bool shadow = wil.z >= 1e-4f;
-        if (shadow) {
-            n = nee_terms(ps.beta);
-            const bool nothing = (n.dL.x == 0.0f) & (n.dL.y == 0.0f) & (n.dL.z == 0.0f) &&
-                                 (!BWD || ((n.bW.x == 0.0f) & (n.bW.y == 0.0f) & (n.bW.z == 0.0f) & (n.fLW.x == 0.0f) & (n.fLW.y == 0.0f) & (n.fLW.z == 0.0f) &
-                                           (n.neeM.x == 0.0f) & (n.neeM.y == 0.0f) & (n.neeM.z == 0.0f) & (fabsf(n.dfLdr) < 3.0e38f)));
-            shadow = !nothing;
-        }
-        if (shadow) COUNT(C_SHADOW_TRACED);                                               // counter 7: shadow rays actually traced
-        stop = sample_bsdf();
-        if (!stop) COUNT(C_CLOSEST);
-        bool occluded;
-        A::shadow_and_closest(S, lds, shadow, it.p, light.wi, 1e-4f, light.dist, !stop, ps.o, ps.d, occluded, h);
-        if (shadow && !occluded) nee_apply(n);
-    } else {
-        const bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
-        if (!occluded && wil.z >= 1e-4f) nee_apply(nee_terms(ps.beta));
-        COUNT(C_SHADOW_TRACED);
-        stop = sample_bsdf();              // the caller traces the continuation ray (path_continue), after it has put pv away
+template <bool BWD>
+ZD NeeTerms nee_terms(const ShadeCtx &x, f3 beta_in) {                            // beta_in: throughput arriving at the vertex
+    NeeTerms n; n.dL = n.bW = n.fLW = n.neeM = mk3(0.0f); n.cL = 0.0f; n.dfLdr = 0.0f;
+    GgxTerms g = ggx_terms(x.wo, x.wil, x.roughness);
+    f3 bsdf = ggx_brdf_from(g, x.wil, x.diffuse);
+    float pb = ggx_pdf_from(g, x.wo, x.wil);
+    float mis = balanced_heuristic(x.light.pdf, pb);
+    float inv_dn = rcp(fmaxf(x.light.pdf, 1e-4f));
+    n.dL = (((beta_in * bsdf) * mis) * x.light.eval) * inv_dn;
+    if (BWD) {
+        f3 W = (x.light.eval * mis) * inv_dn;
+        float dlnpL;
+        n.bW = beta_in * W; n.cL = x.wil.z * ZDR_INV_PI; n.dfLdr = ggx_dfdr_from(g, x.wo, x.wil, x.roughness, dlnpL);
+        n.fLW = bsdf * W;
+        float pbf = (x.light.pdf + pb > 1e-4f) ? pb * rcp(x.light.pdf + pb) : 0.0f;   // d w_nee/dr = -w_nee pb/(pl+pb) dln(pb)/dr
+        n.neeM = ((beta_in * bsdf) * W) * (pbf * dlnpL);
     }
+    return n;
+}
+template <bool BWD>
+ZD void nee_apply(PathState &ps, PathVertex &pv, const NeeTerms &n) {
+    ps.L = ps.L + n.dL;
+    if (BWD) { pv.bW = n.bW; pv.cL = n.cL; pv.dfLdr = n.dfLdr; pv.fLW = n.fLW; pv.neeM = n.neeM; }
+}
+
+// BSDF sampling and Russian roulette (prb.py:69-87); true = the path stops here, else (ps.o, ps.d) is the continuation ray
+template <int SK, bool BWD>
+ZD bool sample_bsdf(const RenderCfg &R, const SamplerCfg &C, const ShadeCtx &x, PathState &ps, const Interaction &it, PathVertex &pv) {
+    float u_lobe = sampler_next<SK>(C, ps.smp);
+    f2 u_dir = sampler_next2<SK>(C, ps.smp);
+    f3 wi_local = ggx_sample(x.wo, x.roughness, u_lobe, u_dir);
+    GgxTerms g = ggx_terms(x.wo, wi_local, x.roughness);
+    ps.pdf_bsdf = ggx_pdf_from(g, x.wo, wi_local);
+    f3 wi = to_world(x.onb, wi_local);
+    bool stop = (dot(wi, it.ng) < 1e-4f) || (wi_local.z < 1e-4f);             // prb.py:73-74
+    const f3 beta_in = ps.beta;
+    float q = 1.0f;
+    int rr_kind = 0;
+    if (!stop) {
+        ps.o = offset_ray_origin(it.p, it.ng); ps.d = wi;
+        f3 f = ggx_brdf_from(g, wi_local, x.diffuse);
+        float inv_p = rcp(ps.pdf_bsdf);
+        ps.beta = ps.beta * (f * inv_p);
+        if (ps.depth >= R.rr_depth) {                                         // prb.py:79-87
+            float l = 0.212671f * ps.beta.x + 0.715160f * ps.beta.y + 0.072169f * ps.beta.z;
+            if (l == 0.0f) stop = true;
+            else {
+                q = fmaxf(l, 0.05f);
+                float r = sampler_next<SK>(C, ps.smp);
+                if (r >= q) stop = true;
+                else { ps.beta = ps.beta * rcp(q); rr_kind = (l >= 1.0f) ? 2 : ((l >= 0.05f) ? 1 : 0); }
+            }
+        }
+        if (BWD && !stop) {
+            float inv_pq = inv_p * rcp(q);
+            pv.bpq = beta_in * inv_pq; pv.c = wi_local.z * ZDR_INV_PI; pv.dfdr = ggx_dfdr_from(g, x.wo, wi_local, x.roughness, pv.dlnp);
+            pv.T = f * inv_pq;
+            // prb.py:83 has no upper clamp on q: for lum(beta') >= 1 the path survives with certainty and is
+            // STILL divided by q = lum(beta'), i.e. beta leaves this vertex with unit luminance.  The forward's
+            // expectation then depends on q(material); the sweep differentiates through it (sweep_vertex).
+            pv.rr = rr_kind;
+            if (rr_kind == 2) pv.bnorm = ps.beta;
+        }
+    }
+    ps.depth++;
+    if (ps.depth >= R.max_depth) stop = true;
     return stop;
+}
+
+// Everything of a vertex that comes BEFORE its rays are traced, in the order the BVH kernels use: the NEE arithmetic
+// first, so that only its results (not the frame, the light sample and the material) have to live through the
+// traversal — and so that the shadow ray can be SKIPPED when nothing rides on it: a light sample below the horizon
+// (prb.py:62) or one that carries exactly nothing even if visible (a light seen from behind or edge-on has eval = 0,
+// light.py:76).  On the Cornell box that is every vertex of the ceiling.  Exact: only all-zero, NaN-free terms are dropped,
+// so the image and the gradients are the reference's bit for bit.  Returns the shadow segment (if any) and whether the
+// path stops at this vertex; the continuation ray is (ps.o, ps.d).
+struct VertexRays { bool shadow, stop; f3 sd; float stmax; };
+template <int SK, bool BWD, bool STATS, bool ENV>
+ZD VertexRays path_vertex_begin(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
+                                PathState &ps, const Interaction &it, PathVertex &pv, NeeTerms &n, Counters &cnt) {
+    const ShadeCtx x = shade_ctx<SK, BWD, STATS, ENV>(S, R, C, io, ps, it, pv, cnt);
+    VertexRays vr; vr.sd = x.light.wi; vr.stmax = x.light.dist;
+    n.dL = n.bW = n.fLW = n.neeM = mk3(0.0f); n.cL = 0.0f; n.dfLdr = 0.0f;
+    COUNT(C_SHADOW);
+    vr.shadow = x.wil.z >= 1e-4f;
+    if (vr.shadow) {
+        n = nee_terms<BWD>(x, ps.beta);
+        const bool nothing = (n.dL.x == 0.0f) & (n.dL.y == 0.0f) & (n.dL.z == 0.0f) &&
+                             (!BWD || ((n.bW.x == 0.0f) & (n.bW.y == 0.0f) & (n.bW.z == 0.0f) & (n.fLW.x == 0.0f) & (n.fLW.y == 0.0f) & (n.fLW.z == 0.0f) &
+                                       (n.neeM.x == 0.0f) & (n.neeM.y == 0.0f) & (n.neeM.z == 0.0f) & (fabsf(n.dfLdr) < 3.0e38f)));
+        vr.shadow = !nothing;
+    }
+    if (vr.shadow) COUNT(C_SHADOW_TRACED);                                          // counter 7: shadow rays actually traced
+    vr.stop = sample_bsdf<SK, BWD>(R, C, x, ps, it, pv);
+    if (!vr.stop) COUNT(C_CLOSEST);
+    return vr;
+}
+
+template <int SK, class A, bool BWD, bool STATS, bool ENV>
+ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int *lds,
+                   PathState &ps, const Interaction &it, PathVertex &pv, Hit &h, Counters &cnt) {
+    if constexpr (A::kFuseRays) {
+        NeeTerms n;
+        const VertexRays vr = path_vertex_begin<SK, BWD, STATS, ENV>(S, R, C, io, ps, it, pv, n, cnt);
+        bool occluded;
+        A::shadow_and_closest(S, lds, vr.shadow, it.p, vr.sd, 1e-4f, vr.stmax, !vr.stop, ps.o, ps.d, occluded, h);
+        if (vr.shadow && !occluded) nee_apply<BWD>(ps, pv, n);
+        return vr.stop;
+    } else {
+        const ShadeCtx x = shade_ctx<SK, BWD, STATS, ENV>(S, R, C, io, ps, it, pv, cnt);
+        COUNT(C_SHADOW);
+        const bool occluded = A::any(S, lds, it.p, x.light.wi, 1e-4f, x.light.dist);
+        if (!occluded && x.wil.z >= 1e-4f) nee_apply<BWD>(ps, pv, nee_terms<BWD>(x, ps.beta));
+        COUNT(C_SHADOW_TRACED);
+        return sample_bsdf<SK, BWD>(R, C, x, ps, it, pv);   // the caller traces the continuation ray (path_continue), after it has put pv away
+    }
 }
 
 // The continuation ray of a vertex whose path goes on: already traced by path_shade when A::kFuseRays.

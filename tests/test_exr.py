@@ -10,7 +10,7 @@ import pytest
 from zdr_amd import exr
 
 
-@pytest.mark.parametrize("compression", [exr.NO_COMPRESSION, exr.ZIPS, exr.ZIP])
+@pytest.mark.parametrize("compression", [exr.NO_COMPRESSION, exr.RLE, exr.ZIPS, exr.ZIP])
 @pytest.mark.parametrize("half", [False, True])
 @pytest.mark.parametrize("shape", [(32, 64, 3), (37, 21, 4), (1, 1, 3)])
 def test_round_trip(tmp_path, compression, half, shape):
@@ -76,3 +76,17 @@ def test_envmap_preparation_accepts_an_exr(tmp_path):
     a = envmap.prepare_image(envmap.load_image(p))
     b = envmap.prepare_image(img)
     assert np.array_equal(a, b)
+
+
+def test_rle_runs_and_literals_decode_as_the_format_document_says():
+    # count byte n >= 0: next byte repeated n + 1 times; n < 0: -n literal bytes
+    coded = bytes([2, 7, 0xFD, 1, 2, 3, 0, 9])
+    assert exr._unrle(coded) == bytes([7, 7, 7, 1, 2, 3, 9])
+    raw = bytes([5] * 300 + list(range(40)) + [8, 8, 8, 8, 1])
+    assert exr._unrle(exr._rle(raw)) == raw
+
+
+def test_constant_image_round_trips_through_rle(tmp_path):
+    p = str(tmp_path / "c.exr")
+    exr.write_exr(p, np.full((8, 64, 3), 2.5, np.float32), compression=exr.RLE)
+    assert np.array_equal(exr.read_exr(p), np.full((8, 64, 3), 2.5, np.float32))

@@ -1,7 +1,7 @@
 """Minimal OpenEXR reader / writer for environment maps (Scene.add_envmap; the reference reads its EXR files with
 imageio, /root/reference/envmap.py:117-121, which this environment does not ship).
 
-Scope: single-part scan-line files, channels of type HALF / FLOAT / UINT with sampling 1, compression NONE, ZIPS or ZIP
+Scope: single-part scan-line files, channels of type HALF / FLOAT / UINT with sampling 1, compression NONE, RLE, ZIPS or ZIP
 (what Blender, OpenEXR's own tools and most HDRI libraries write by default or on request).  PIZ, PXR24, B44 and DWA
 files are refused with a message naming the compression.  Layout per the OpenEXR file-layout document: magic 0x01312f76,
 version word, attribute list, chunk-offset table, chunks {y, size, data}; inside a chunk the scan lines follow one
@@ -17,8 +17,8 @@ import numpy as np
 
 MAGIC = 20000630
 NO_COMPRESSION, RLE, ZIPS, ZIP, PIZ, PXR24, B44, B44A, DWAA, DWAB = range(10)
-_NAMES = {RLE: "RLE", PIZ: "PIZ", PXR24: "PXR24", B44: "B44", B44A: "B44A", DWAA: "DWAA", DWAB: "DWAB"}
-_LINES = {NO_COMPRESSION: 1, ZIPS: 1, ZIP: 16}
+_NAMES = {PIZ: "PIZ", PXR24: "PXR24", B44: "B44", B44A: "B44A", DWAA: "DWAA", DWAB: "DWAB"}
+_LINES = {NO_COMPRESSION: 1, RLE: 1, ZIPS: 1, ZIP: 16}
 _DTYPES = {0: np.dtype("<u4"), 1: np.dtype("<f2"), 2: np.dtype("<f4")}      # UINT, HALF, FLOAT
 
 
@@ -27,12 +27,38 @@ def _cstr(buf: bytes, pos: int):
     return buf[pos:end].decode("latin-1"), end + 1
 
 
-def _unzip(data: bytes, size: int) -> bytes:
-    if len(data) == size:                       # stored raw when deflate did not help
-        return data
-    t = np.frombuffer(zlib.decompress(data), np.uint8)
-    if t.size != size:
-        raise ValueError("EXR: corrupt ZIP chunk")
+def _unrle(data: bytes) -> bytes:
+    """OpenEXR run-length coding: a count byte n >= 0 is followed by one byte repeated n + 1 times, n < 0 by -n literal bytes."""
+    out = bytearray()
+    i = 0
+    while i < len(data):
+        n = data[i] - 256 if data[i] > 127 else data[i]
+        i += 1
+        if n < 0:
+            out += data[i:i - n]; i -= n
+        else:
+            out += bytes([data[i]]) * (n + 1); i += 1
+    return bytes(out)
+
+
+def _rle(raw: bytes) -> bytes:
+    out = bytearray()
+    i, n = 0, len(raw)
+    while i < n:
+        j = i + 1
+        while j < n and raw[j] == raw[i] and j - i < 128:
+            j += 1
+        if j - i >= 3:
+            out += bytes([j - i - 1, raw[i]]); i = j
+        else:
+            j = i
+            while j < n and j - i < 127 and not (j + 2 < n and raw[j] == raw[j + 1] == raw[j + 2]):
+                j += 1
+            out += bytes([256 - (j - i)]) + raw[i:j]; i = j
+    return bytes(out)
+
+
+def _unpredict(t: np.ndarray, size: int) -> bytes:
     # predictor: t[i] = t[i-1] + t[i] - 128 (mod 256), then the halves hold the even and the odd bytes
     t = np.cumsum(t.astype(np.int64) - 128, dtype=np.int64)
     t = ((t + 128) & 0xFF).astype(np.uint8)
@@ -43,13 +69,27 @@ def _unzip(data: bytes, size: int) -> bytes:
     return out.tobytes()
 
 
-def _zip(raw: bytes) -> bytes:
+def _predict(raw: bytes) -> np.ndarray:
     a = np.frombuffer(raw, np.uint8)
     t = np.concatenate([a[0::2], a[1::2]]).astype(np.int64)
     d = np.empty_like(t)
     d[0] = t[0]
     d[1:] = t[1:] - t[:-1] + 128
-    comp = zlib.compress((d & 0xFF).astype(np.uint8).tobytes())
+    return (d & 0xFF).astype(np.uint8)
+
+
+def _unzip(data: bytes, size: int, rle: bool = False) -> bytes:
+    if len(data) == size:                       # stored raw when the coder did not help
+        return data
+    t = np.frombuffer(_unrle(data) if rle else zlib.decompress(data), np.uint8)
+    if t.size != size:
+        raise ValueError("EXR: corrupt compressed chunk")
+    return _unpredict(t, size)
+
+
+def _zip(raw: bytes, rle: bool = False) -> bytes:
+    d = _predict(raw).tobytes()
+    comp = _rle(d) if rle else zlib.compress(d)
     return comp if len(comp) < len(raw) else raw
 
 
@@ -79,7 +119,7 @@ def read_exr(path: str) -> np.ndarray:
         channels.append((name, _DTYPES[ptype]))
     comp = attrs["compression"][1][0]
     if comp not in _LINES:
-        raise NotImplementedError(f"{path}: {_NAMES.get(comp, comp)} compression is not supported (NONE, ZIPS and ZIP are); re-save the file, e.g. `oiiotool in.exr --compression zip -o out.exr`")
+        raise NotImplementedError(f"{path}: {_NAMES.get(comp, comp)} compression is not supported (NONE, RLE, ZIPS and ZIP are); re-save the file, e.g. `oiiotool in.exr --compression zip -o out.exr`")
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     W, H = x1 - x0 + 1, y1 - y0 + 1
     nlines = _LINES[comp]
@@ -91,7 +131,7 @@ def read_exr(path: str) -> np.ndarray:
         y, size = struct.unpack_from("<ii", buf, off)
         rows = min(nlines, y1 - y + 1)
         data = buf[off + 8:off + 8 + size]
-        raw = data if comp == NO_COMPRESSION else _unzip(data, rows * line_bytes)
+        raw = data if comp == NO_COMPRESSION else _unzip(data, rows * line_bytes, rle=(comp == RLE))
         q = 0
         for r in range(rows):
             for name, dt in channels:           # the file lists (and stores) channels alphabetically
@@ -111,7 +151,7 @@ def write_exr(path: str, image: np.ndarray, compression: int = ZIP, half: bool =
     names = ["R", "G", "B", "A"][:C]
     dt = np.dtype("<f2") if half else np.dtype("<f4")
     if compression not in _LINES:
-        raise NotImplementedError("write_exr: NONE, ZIPS or ZIP")
+        raise NotImplementedError("write_exr: NONE, RLE, ZIPS or ZIP")
     chl = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", 1 if half else 2, 0, 1, 1) for n in sorted(names)) + b"\0"
     box = struct.pack("<4i", 0, 0, W - 1, H - 1)
 
@@ -126,7 +166,7 @@ def write_exr(path: str, image: np.ndarray, compression: int = ZIP, half: bool =
     for y in range(0, H, nlines):
         rows = min(nlines, H - y)
         raw = b"".join(img[y + r, :, names.index(n)].astype(dt).tobytes() for r in range(rows) for n in sorted(names))
-        data = raw if compression == NO_COMPRESSION else _zip(raw)
+        data = raw if compression == NO_COMPRESSION else _zip(raw, rle=(compression == RLE))
         chunks.append(struct.pack("<ii", y, len(data)) + data)
     table_at = len(head)
     offs, at = [], table_at + 8 * len(chunks)

@@ -683,7 +683,7 @@ static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
 static int ensure_ring(zdr_scene *s, hipStream_t st) {
     size_t need = (size_t)ZDR_MAX_PERSISTENT_BLOCKS * ZDR_RING_CAP * 2 * 64 * sizeof(float4);
     if (need > s->ring_bytes) {
-        (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); s->d_ring = nullptr; s->ring_bytes = 0;
+        (void)hipFree(s->d_ring); s->d_ring = nullptr; s->ring_bytes = 0;
         HIPCHK(hipMalloc((void **)&s->d_ring, need));
         s->ring_bytes = need;
     }

@@ -479,3 +479,15 @@ def test_rccl_single_rank_exchange(mat_a):
         assert torch.equal(g, m.grad) and float(g.abs().sum()) > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_texture_optimisation_example_converges(tmp_path):
+    """examples/optimize_texture.py = the workflow of the reference's example.py (target render, random material, Adam
+    through scene.render / PRB backward): the image loss must fall."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("optimize_texture", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "optimize_texture.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    losses = mod.run(iters=40, res=96, spp=8, tex=64, out=str(tmp_path), verbose=False)
+    assert np.mean(losses[-5:]) < 0.75 * losses[0], (losses[0], losses[-5:])      # the Monte-Carlo noise of an 8-spp render sets the floor
+    assert os.path.exists(tmp_path / "result.png") and os.path.exists(tmp_path / "footprints.png")

@@ -165,7 +165,8 @@ int zdr_sampler_dump(zdr_scene *scene, int32_t sampler, uint32_t seed, uint32_t 
  *   header  {bits(nvert), L.rgb — the sample's radiance before the clamp of integrator.py:26 —, 0, Li.rgb of the emitter that ended it}
  *   vertex  {bits(inst), bits(prim), uv.xy, bits(flags), pdf_bsdf, wi.xyz (world), beta.rgb leaving the vertex,
  *            grad.rgba (what the backward pass scatters at uv for this vertex), NEE radiance.rgb, 0 x 5}
- *   flags = light sample accepted | path went on << 1 | Russian roulette kind << 2 (0 none, 1 stochastic, 2 renormalising). */
+ *   flags = light sample accepted | path went on << 1 | Russian roulette kind << 2 (0 none, 1 stochastic, 2 renormalising).
+ * A query whose pixel lies outside the image or whose sample_index >= spp yields an all-zero row. */
 int zdr_path_dump(zdr_scene *scene, const zdr_render_params *params, const float *material, const float *d_image,
                   const int32_t *queries, uint32_t n, int32_t maxv, float *out, void *stream);
 

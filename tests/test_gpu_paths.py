@@ -110,3 +110,17 @@ def test_environment_paths(cbox_arrays):
     what = "cbox + environment, material B"
     cons, st, fl = run_case(scene, S, Sf, mat, 32, 32, 16, 8, what)
     check(cons, st, fl, what, tight=False)
+
+
+def test_queries_outside_the_render_read_as_zero_rows():
+    """zdr.h, zdr_path_dump: a pixel outside the image or a sample index >= spp must not be walked (the cotangent
+    would be read out of bounds); the row is all zeros and the valid rows are untouched by their neighbours."""
+    scene = make_scene("path")
+    m = torch.from_numpy(fd_material_np(64, 0)).cuda()
+    W, H, spp = 16, 8, 4
+    q = torch.tensor([[3, 2, 1], [-1, 0, 0], [W, 0, 0], [0, H, 0], [0, -5, 0], [0, 0, spp], [3, 2, 1]], dtype=torch.int32).cuda()
+    cot = torch.ones((H, W, 4), device="cuda")
+    out = scene.path_dump(m, q, (W, H), spp, 3, d_image=cot, maxv=4).cpu().numpy()
+    assert np.all(out[1:6] == 0.0)
+    assert np.array_equal(out[0], out[6]) and np.any(out[0] != 0.0)
+    scene.check()

@@ -41,7 +41,7 @@ static void normal_matrix(const float *m, float *n) {      // inverse(transpose(
 }
 
 // ------------------------------------------------------------------------------ BVH builder
-// Binned SAH (16 bins, 3 axes), leaves of <= ZDR_BVH_LEAF triangles, depth bounded by the traversal stack.
+// Binned SAH (ZDR_BVH_BINS bins, 3 axes), leaves of <= ZDR_BVH_LEAF triangles, depth bounded by the traversal stack.
 #ifndef ZDR_BVH_BINS
 #define ZDR_BVH_BINS 32   // 1 M triangles, path fwd / bwd ms at 1024^2 spp 32: 16 bins 33.9 / 44.1, 32 bins 33.5 / 43.7
 #endif
@@ -313,7 +313,7 @@ struct zdr_scene {
     float4 *d_env_tex = nullptr; float *d_alias_prob = nullptr, *d_env_pdf = nullptr; int32_t *d_alias_idx = nullptr;
     float4 *d_partial = nullptr; size_t partial_bytes = 0;
     unsigned long long *d_tile_masks = nullptr; size_t tile_mask_bytes = 0;   // camera-ray candidate pairs per tile (k_tile_masks)
-    float tile_mask_key[24]; bool tile_mask_key_set = false;                  // camera + shard the masks in the buffer were built for
+    float tile_mask_key[24]; bool tile_mask_key_set = false;                  // camera + tile grid the masks in the buffer were built for (all tiles of the rectangle, whatever the shard)
     unsigned int *d_work_counters = nullptr;
     float4 *d_ring = nullptr; size_t ring_bytes = 0;     // primary rings of the path kernels (integrators.h)
     float *d_cells = nullptr; size_t cells_bytes = 0;       // backward staging cells, (tex_h+1) x (tex_w+1) x 16 floats

@@ -666,6 +666,7 @@ __global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, Sampl
     for (int k = 0; k < stride; k++) o[k] = 0.0f;
     const int px = queries[3 * i], py = queries[3 * i + 1];
     const uint32_t idx = (uint32_t)queries[3 * i + 2];
+    if (px < 0 || py < 0 || px >= R.width || py >= R.height || idx >= C.spp) return;   // a query outside the image / sample range reads as all zeros
     Counters cnt;
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)px, (uint32_t)py, C.seed, 0u) : 0u;
     PathState ps;

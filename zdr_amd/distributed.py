@@ -133,7 +133,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if torch.cuda.is_available():        # one GPU per rank, whatever the backend (RCCL requires it; gloo stages through the host)
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

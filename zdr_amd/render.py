@@ -67,6 +67,9 @@ class Scene:
         self.light_count = int((arrays.inst_emission > 0).any(axis=1).sum())
         h = C.c_void_p()
         L = N.lib()
+        if getattr(self, "_finalizer", None) is not None:   # a second load_geometry: the old handle (and the tables set on it) go
+            self._finalizer()
+            self._handle, self.env_count, self._pmj_tables_set = None, 0, False
         N.check(L.zdr_scene_create(arrays.verts.ctypes.data, arrays.verts.shape[0], arrays.tris.ctypes.data, arrays.tris.shape[0],
                                    arrays.inst_tri_begin.ctypes.data, arrays.inst_xform.ctypes.data, arrays.inst_emission.ctypes.data,
                                    arrays.ninst, self.device.index, N.ACCELS[accel], C.byref(h)))
@@ -156,6 +159,8 @@ class Scene:
             image = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=self.device)
         else:
             image = out
+            if image.shape != (res[1], res[0], 4) or image.dtype != torch.float32 or image.device != self.device or not image.is_contiguous():
+                raise ValueError(f"out must be a contiguous float32 ({res[1]}, {res[0]}, 4) tensor on {self.device}")
         p = self._params(res, spp, seed, material.shape[0:2], rect, samples, integrator=kernel, tile_shard=tile_shard)
         N.check(N.lib().zdr_render_forward(self._handle, C.byref(p), material.data_ptr(), image.data_ptr(), self._stream()))
         return image
@@ -164,8 +169,10 @@ class Scene:
         """render.py:176-199: accumulates into ``d_material``; uses ``seed + 1`` like the reference (:196)."""
         self._check_material(material)
         material = material.detach().contiguous()
-        g = grad_output.reshape(res[1], res[0], 4).contiguous()
+        g = grad_output.reshape(res[1], res[0], 4).to(device=self.device, dtype=torch.float32).contiguous()
         assert d_material.is_contiguous() and d_material.shape == material.shape
+        if d_material.device != self.device or d_material.dtype != torch.float32:
+            raise ValueError(f"d_material must be a float32 tensor on {self.device}")
         p = self._params(res, spp, seed + 1, material.shape[0:2], rect, samples, camera, tile_shard=tile_shard)
         N.check(N.lib().zdr_render_backward(self._handle, C.byref(p), g.data_ptr(), material.data_ptr(), d_material.data_ptr(), self._stream()))
         return d_material, None, None, None, None
@@ -219,9 +226,13 @@ class Scene:
         N.check(N.lib().zdr_scene_check(self._handle, self._stream()))
 
     # ------------------------------------------------------------------- test / debug hooks
+    def _rays(self, rays):
+        assert rays.ndim == 2 and rays.shape[1] == 8
+        return rays.to(device=self.device, dtype=torch.float32).contiguous()
+
     def trace_closest(self, rays):
         """rays: (n, 8) float32 cuda {o, tmin, d, tmax} -> (inst_prim (n,2) int32, bary_t (n,3) float32)."""
-        rays = rays.contiguous()
+        rays = self._rays(rays)
         n = rays.shape[0]
         ip = torch.empty((n, 2), dtype=torch.int32, device=self.device)
         bt = torch.empty((n, 3), dtype=torch.float32, device=self.device)
@@ -229,14 +240,14 @@ class Scene:
         return ip, bt
 
     def trace_any(self, rays):
-        rays = rays.contiguous()
+        rays = self._rays(rays)
         occ = torch.empty((rays.shape[0],), dtype=torch.int32, device=self.device)
         N.check(N.lib().zdr_trace_any(self._handle, rays.data_ptr(), rays.shape[0], occ.data_ptr(), self._stream()))
         return occ
 
     def sampler_dump(self, queries, spp, seed=0, nvert=3, rr_depth=RR_DEPTH):
         """queries: (n, 3) int32 cuda {px, py, sample_index} -> (n, 2 + 8*nvert) float32 sampler draws."""
-        q = queries.to(torch.int32).contiguous()
+        q = queries.reshape(-1, 3).to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty((q.shape[0], 2 + 8 * nvert), dtype=torch.float32, device=self.device)
         N.check(N.lib().zdr_sampler_dump(self._handle, N.SAMPLERS[self.sampler], int(seed) & 0xFFFFFFFF, int(spp), q.data_ptr(), q.shape[0], nvert, rr_depth, out.data_ptr(), self._stream()))
         return out
@@ -246,9 +257,9 @@ class Scene:
         (n, 8 + 24 maxv) float32.  ``seed`` is used as it is (pass seed + 1 for the paths of a backward pass)."""
         self._check_material(material)
         material = material.detach().contiguous()
-        q = queries.to(torch.int32).contiguous()
+        q = queries.reshape(-1, 3).to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty((q.shape[0], 8 + 24 * maxv), dtype=torch.float32, device=self.device)
         p = self._params(res, spp, seed, material.shape[0:2])
-        g = None if d_image is None else d_image.reshape(res[1], res[0], 4).contiguous()
+        g = None if d_image is None else d_image.reshape(res[1], res[0], 4).to(device=self.device, dtype=torch.float32).contiguous()
         N.check(N.lib().zdr_path_dump(self._handle, C.byref(p), material.data_ptr(), None if g is None else g.data_ptr(), q.data_ptr(), q.shape[0], maxv, out.data_ptr(), self._stream()))
         return out

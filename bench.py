@@ -92,14 +92,15 @@ def cpu_baseline(scene, mat_np, W, spp_sample):
     import oracle
     from gpu_util import oracle_params
     S = oracle.OracleScene.from_arrays(scene._arrays)
-    p = oracle_params(scene, W, W, spp_sample, 0, mat_np.shape[:2])
+    threads = len(os.sched_getaffinity(0))                  # the CPUs this process may run on = the OpenMP threads asked for
+    p = oracle_params(scene, W, W, spp_sample, 0, mat_np.shape[:2], nthreads=threads)
     t0 = time.time()
     S.render_forward(p, mat_np)
     t1 = time.time()
-    S.render_backward(oracle_params(scene, W, W, spp_sample, 1, mat_np.shape[:2]), np.ones((W, W, 4), np.float32), mat_np)
+    S.render_backward(oracle_params(scene, W, W, spp_sample, 1, mat_np.shape[:2], nthreads=threads), np.ones((W, W, 4), np.float32), mat_np)
     t2 = time.time()
     n = W * W * spp_sample
-    return {"value": round(2 * n / (t2 - t0) / 1e6, 3), "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(2 * n / (t2 - t0) / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": f"{scene.integrator} {W}x{W} spp={spp_sample} fwd+bwd ({2 * n / 1e6:.1f} Msamples) of the same scene, oracle/zdr_oracle.c with OpenMP",
             "fwd_msamples_s": round(n / (t1 - t0) / 1e6, 3), "bwd_msamples_s": round(n / (t2 - t1) / 1e6, 3)}
 

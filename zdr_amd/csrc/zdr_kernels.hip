@@ -280,6 +280,11 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
     __shared__ uint32_t lds_perm[2 * WAVE];                 // per item bank (see k_path): CMJ seeds, tile origin,
     __shared__ int lds_origin[4];
     __shared__ float lds_leg[2 * 3 * WAVE];                 // and the pixel cotangents / spp
+#ifdef ZDR_BWD_LDS_PAD                                      // experiment: what fewer waves per CU cost (profiles/r2_bwd_occupancy.txt)
+    __shared__ float lds_pad[ZDR_BWD_LDS_PAD];
+    if (R.width < 0) lds_pad[threadIdx.x] = 1.0f;
+    if (R.height < 0) io.cells[0] = lds_pad[threadIdx.x ^ 1];
+#endif
     const int lane = threadIdx.x;
     const int lds_vertices = (R.rr_depth < LV) ? max(R.rr_depth, 0) : LV;   // LDS records carry no RR fields
     Counters cnt;

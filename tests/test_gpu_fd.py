@@ -50,3 +50,28 @@ def test_ad_matches_fd_for_roughness_within_resolution():
     ad, fd, sigma = directional(scene, material, delta, W, 4096, 12, wimg)
     print(f"[fd] path roughness: AD {ad:.3f} FD {fd:.3f} rel {abs(ad - fd) / abs(fd):.2e} (1 sigma {sigma / abs(fd):.2e})")
     assert abs(ad - fd) <= 4 * sigma and abs(ad - fd) <= 1e-2 * abs(fd) + 2 * sigma
+
+
+@pytest.mark.parametrize("what", ["environment", "three lights"])
+@pytest.mark.parametrize("integrator", ["path", "direct"])
+def test_ad_matches_fd_with_an_environment_map_and_with_several_lights(integrator, what):
+    """The adjoint of the OTHER light-sampling branches — the environment's alias-table sampling with its MIS weights
+    (envmap.py:150-203) and sample_light over several emitters of different sizes (light.py:33-48) — against finite
+    differences of the forward render, all four material channels at once (long form: tools/fd_directional.py
+    --scene env|lights3, profiles/r2_fd_directional_env_lights.txt)."""
+    if what == "environment":
+        from test_envmap import sun_sky
+        scene = make_scene(integrator)
+        scene.add_envmap(sun_sky())
+    else:
+        from gpu_util import multi_light_arrays
+        scene = make_scene(integrator, arrays=multi_light_arrays())
+    material = torch.from_numpy(fd_material_np(1024, 0)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    W = 256
+    wimg = torch.rand((W, W, 4), device="cuda", generator=g) + 0.5; wimg[..., 3] = 0
+    delta = torch.rand(material.shape, device="cuda", generator=g)
+    ad, fd, sigma = directional(scene, material, delta, W, 2048, 8, wimg)
+    print(f"[fd] {integrator}, {what}, all channels: AD {ad:.3f} FD {fd:.3f} rel {abs(ad - fd) / abs(fd):.2e} (1 sigma {sigma / abs(fd):.2e})")
+    assert abs(ad - fd) <= 1e-3 * abs(fd) + 3 * sigma
+    scene.check()

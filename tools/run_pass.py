@@ -16,8 +16,13 @@ ap.add_argument("--spp", type=int, default=256)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--accel", default="auto")
 ap.add_argument("--material", default="A")
+ap.add_argument("--env", action="store_true", help="add a sun-and-sky environment map (the ENV kernel instantiations)")
 a = ap.parse_args()
 scene = make_scene(a.integrator, accel=a.accel)
+if a.env:
+    import numpy as np
+    sky = np.random.default_rng(0).uniform(0.05, 0.6, (32, 64, 3)).astype(np.float32); sky[5:8, 40:44] = (300.0, 260.0, 200.0)
+    scene.add_envmap(sky)
 m = torch.from_numpy(cbox_material_np() if a.material == "A" else fd_material_np(1024, 0)).cuda()
 W = a.res
 ones = torch.ones((W, W, 4), device="cuda")

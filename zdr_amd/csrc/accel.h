@@ -10,13 +10,16 @@
 
 // __launch_bounds__ second argument of the path kernels = minimum waves per SIMD (caps the VGPR budget at 512 / n)
 #ifndef ZDR_MIN_WAVES
-#define ZDR_MIN_WAVES 3
+#define ZDR_MIN_WAVES 4        // cbox 512^2 spp 256 forward with 3 / 4 / 5 waves per SIMD: 9.8 / 9.1 / 10.3 ms (127 VGPRs and no spills at 4; profiles/r2_fwd_occupancy.txt)
+#endif
+#ifndef ZDR_MIN_WAVES_ENV
+#define ZDR_MIN_WAVES_ENV 4    // the environment-light instantiation: 10 registers spilled at 4, still 11.9 -> 11.4 ms
 #endif
 #ifndef ZDR_MIN_WAVES_BVH
 #define ZDR_MIN_WAVES_BVH 6    // 1 M triangles, forward ms at 1024^2 spp 32 with 4 / 5 / 6 / 7 / 8 waves per SIMD: 32.8 / 31.4 / 30.3 / 31.4 / 39.4
 #endif
 #ifndef ZDR_MIN_WAVES_BWD
-#define ZDR_MIN_WAVES_BWD ZDR_MIN_WAVES
+#define ZDR_MIN_WAVES_BWD 3    // LDS holds 12 waves per CU; 4 here = 128 VGPRs with 11 spilled: 14.9 -> 15.6 ms (profiles/r2_bwd_occupancy.txt)
 #endif
 #ifndef ZDR_MIN_WAVES_BWD_BVH
 #define ZDR_MIN_WAVES_BWD_BVH 4
@@ -100,7 +103,7 @@ ZD PairHit pair_test(const_v4f_ptr q, f3 o, f3 d) {
 
 struct BruteAccel {
     static constexpr bool kNeedsLds = false;
-    static constexpr int kMinWavesFwd = ZDR_MIN_WAVES;       // issue-bound: more waves per SIMD buy nothing
+    static constexpr int kMinWavesFwd = ZDR_MIN_WAVES, kMinWavesFwdEnv = ZDR_MIN_WAVES_ENV;
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD;
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES;    // scratch records thrash L2 on cbox (1 instead of 2: 16.7 -> 19.0 ms)
     static constexpr bool kFuseRays = false;                 // one walk over the pairs for both rays of a vertex measured no gain
@@ -172,6 +175,7 @@ ZD float qbox_entry(uint32_t nxq, uint32_t nyq, uint32_t nzq, uint32_t fxq, uint
 
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
+    static constexpr int kMinWavesFwdEnv = ZDR_MIN_WAVES_BVH;
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // 6 waves per SIMD (<= 80 VGPRs: the path state that is cold during the walk is spilled around it); sweep at ZDR_MIN_WAVES_BVH
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES_BVH;    // <= 128 VGPRs give 15 waves per CU instead of 11 (109 -> 94 ms on 1 M triangles)

@@ -165,7 +165,7 @@ struct ItemBanks {
 };
 
 template <int SK, class A, bool STATS, bool ENV>
-__global__ __launch_bounds__(WAVE, A::kMinWavesFwd) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ uint32_t lds_perm[2 * WAVE];
     __shared__ int lds_origin[4];
@@ -414,7 +414,11 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
 
 // ---------------------------------------------------------------------- direct / collocated
 template <int INTEG, int SK, class A, bool BWD, bool STATS, bool ENV>
-__global__ __launch_bounds__(WAVE) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+#ifndef ZDR_MIN_WAVES_DIRECT
+#define ZDR_MIN_WAVES_DIRECT 4   // brute-force direct kernels, cbox 512^2 spp 64: 153 VGPRs (3 waves per SIMD) 1.175 / 1.331 ms, 128 VGPRs (6 spilled) 1.110 / 1.267 ms
+#endif
+// (the environment instantiations take 170 VGPRs: bounded to 3 waves per SIMD, which costs no spill, instead of the 2 the compiler settles for)
+__global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV ? 3 : ZDR_MIN_WAVES_DIRECT) : 1) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 1];
     const WorkItem w = decode_block(R);

@@ -72,19 +72,28 @@ ZD void hit_barycentrics(const DScene &S, Hit &h, f3 o, f3 d) {
 // ---- packed pair test -------------------------------------------------------------------------
 // On gfx950 an fp32 VALU instruction occupies its SIMD for 4 cycles per wave64 whether it is v_fma_f32
 // or v_pk_fma_f32 (profiles/r1_valu_issue_rate.txt): the packed forms do two floats per lane for the
-// price of one.  The brute-force loops therefore test TWO triangles per trip, one in each half of a
-// float2: S.pairs holds, per pair of slots (2k, 2k+1), six float4
-//   {Nx Nx' Ny Ny'} {Nz Nz' Nw Nw'} {Ux Ux' Uy Uy'} {Uz Uz' Uw Uw'} {Vx Vx' Vy Vy'} {Vz Vz' Vw Vw'}
-// (the plane-form records of isect, interleaved).  They are wave-uniform and arrive as SGPR pairs,
-// the ray is broadcast to both halves through op_sel.  An odd triangle count is padded with an
-// all-zero record (0 * inf = NaN fails every comparison).
+// price of one.  The brute-force loops therefore test TWO primitives per trip, one in each half of a
+// float2.  A primitive is a planar convex QUAD — two triangles that the host found to share an edge and a
+// plane (zdr_api.cpp, find_quads): slots 2q and 2q + 1 — or a single triangle: one plane N, one hit point,
+// and four edge functions e = n.p + d that are all >= 0 inside: u and v of both triangles of a quad (their
+// corners are ordered so that the shared diagonal is the w = 0 edge of both), or u, v, w, w of a single
+// triangle.  39 VALU per pair of primitives in the any-hit walk, i.e. for up to FOUR triangles, against 31
+// per pair of triangles; the Cornell box is 15 quads and 2 triangles: 9 trips instead of 16.  S.pairs holds per
+// pair of primitives (2k, 2k+1) ten float4
+//   {Nx Nx' Ny Ny'} {Nz Nz' Nw Nw'}  and for each of the four edge functions  {Ex Ex' Ey Ey'} {Ez Ez' Ew Ew'}.
+// They are wave-uniform and arrive as SGPR pairs, the ray is broadcast to both halves through op_sel.  An odd
+// primitive count is padded with an all-zero record (0 * inf = NaN fails every comparison).  Which triangle of
+// a quad was hit is decided afterwards, for the winner only (brute_resolve): the first one unless the point
+// lies beyond its diagonal.  Hits on the outer edges and on the plane are the triangles' own arithmetic (same
+// records, same fmaf order as tri_test); a ray through the quad's second triangle uses the plane of the first,
+// which the host accepted as the same plane to 5e-7 of the quad's size (float32 rounding of the corners).
 typedef float v2f __attribute__((ext_vector_type(2)));
 ZD v2f splat(float a) { v2f r = {a, a}; return r; }
 ZD v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-struct PairHit { v2f t, c; };   // c >= 0 <=> barycentrics inside; t = ray parameter
+struct PairHit { v2f t, c; };   // c >= 0 <=> inside all four edges; t = ray parameter
 ZD PairHit pair_test(const_v4f_ptr q, f3 o, f3 d) {
-    v4f q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+    v4f q0 = q[0], q1 = q[1];
     v2f dx = splat(d.x), dy = splat(d.y), dz = splat(d.z), ox = splat(o.x), oy = splat(o.y), oz = splat(o.z);
     v2f nd = pfma(q1.xy, dz, pfma(q0.zw, dy, q0.xy * dx));
     v2f no = pfma(q1.xy, oz, pfma(q0.zw, oy, q0.xy * ox));
@@ -93,12 +102,31 @@ ZD PairHit pair_test(const_v4f_ptr q, f3 o, f3 d) {
     PairHit h;
     h.t = tn * r;
     v2f px = pfma(dx, h.t, ox), py = pfma(dy, h.t, oy), pz = pfma(dz, h.t, oz);
-    v2f uu = pfma(q3.xy, pz, pfma(q2.zw, py, q2.xy * px)) + q3.zw;
-    v2f vv = pfma(q5.xy, pz, pfma(q4.zw, py, q4.xy * px)) + q5.zw;
-    v2f m = splat(1.0f) - (uu + vv);
-    h.c.x = fminf(fminf(uu.x, vv.x), m.x);   // v_min3_f32; a NaN here implies a NaN or infinite t, which the range test rejects
-    h.c.y = fminf(fminf(uu.y, vv.y), m.y);
+    v2f e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v4f a = q[2 + 2 * k], b = q[3 + 2 * k];
+        e[k] = pfma(b.xy, pz, pfma(a.zw, py, a.xy * px)) + b.zw;
+    }
+    h.c.x = fminf(fminf(fminf(e[0].x, e[1].x), e[2].x), e[3].x);   // v_min3_f32 + v_min_f32; a NaN here implies a NaN or infinite t, which the range test rejects
+    h.c.y = fminf(fminf(fminf(e[0].y, e[1].y), e[2].y), e[3].y);
     return h;
+}
+
+// primitive of the pair walk -> slot and barycentrics of the triangle that was hit
+ZD void brute_resolve(const DScene &S, Hit &h, int prim, f3 o, f3 d) {
+    if (prim < 0) { h.slot = -1; return; }
+    const bool quad = prim < S.nquads2;
+    int slot = quad ? 2 * prim : prim + S.nquads2;
+    const f3 p = o + d * h.t;
+    float4 U = S.isect[3 * (size_t)slot + 1], V = S.isect[3 * (size_t)slot + 2];
+    float u = U.x * p.x + U.y * p.y + U.z * p.z + U.w, v = V.x * p.x + V.y * p.y + V.z * p.z + V.w;
+    if (quad && 1.0f - (u + v) < 0.0f) {                       // beyond the diagonal: the quad's second triangle
+        slot += 1;
+        U = S.isect[3 * (size_t)slot + 1]; V = S.isect[3 * (size_t)slot + 2];
+        u = U.x * p.x + U.y * p.y + U.z * p.z + U.w; v = V.x * p.x + V.y * p.y + V.z * p.z + V.w;
+    }
+    h.slot = slot; h.u = u; h.v = v;
 }
 
 struct BruteAccel {
@@ -109,16 +137,17 @@ struct BruteAccel {
     static constexpr bool kFuseRays = false;                 // one walk over the pairs for both rays of a vertex measured no gain
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
+        int prim = -1;
         const_v4f_ptr q = as_constant(S.pairs);
 #pragma unroll 1
-        for (int s = 0; s < S.ntris; s += 2, q += 6) {
+        for (int s = 0; s < S.nquads; s += 2, q += 10) {
             PairHit ph = pair_test(q, o, d);
             bool ok = (ph.t.x > tmin) & (ph.t.x < h.t) & (ph.c.x >= 0.0f);
-            h.t = ok ? ph.t.x : h.t; h.slot = ok ? s : h.slot;
+            h.t = ok ? ph.t.x : h.t; prim = ok ? s : prim;
             ok = (ph.t.y > tmin) & (ph.t.y < h.t) & (ph.c.y >= 0.0f);
-            h.t = ok ? ph.t.y : h.t; h.slot = ok ? s + 1 : h.slot;
+            h.t = ok ? ph.t.y : h.t; prim = ok ? s + 1 : prim;
         }
-        hit_barycentrics(S, h, o, d);
+        brute_resolve(S, h, prim, o, d);
         return h;
     }
     // Camera rays of one 8x8 tile: only the pairs whose bit is set in the tile's mask can be hit
@@ -126,6 +155,7 @@ struct BruteAccel {
     ZD static Hit closest_camera(const DScene &S, int *, f3 o, f3 d, unsigned long long mask) {
         if (S.ntris > 128) return closest(S, nullptr, o, d, 0.0f, 1e30f);   // more pairs than mask bits
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = 1e30f;
+        int prim = -1;
         const_v4f_ptr base = as_constant(S.pairs);
         unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mask), hi = __builtin_amdgcn_readfirstlane((unsigned)(mask >> 32));
         unsigned long long m = ((unsigned long long)hi << 32) | lo;
@@ -133,21 +163,21 @@ struct BruteAccel {
         while (m) {
             const int k = __builtin_ctzll(m);
             m &= m - 1ull;
-            PairHit ph = pair_test(base + 6 * k, o, d);
+            PairHit ph = pair_test(base + 10 * k, o, d);
             const int s = 2 * k;
             bool ok = (ph.t.x > 0.0f) & (ph.t.x < h.t) & (ph.c.x >= 0.0f);
-            h.t = ok ? ph.t.x : h.t; h.slot = ok ? s : h.slot;
+            h.t = ok ? ph.t.x : h.t; prim = ok ? s : prim;
             ok = (ph.t.y > 0.0f) & (ph.t.y < h.t) & (ph.c.y >= 0.0f);
-            h.t = ok ? ph.t.y : h.t; h.slot = ok ? s + 1 : h.slot;
+            h.t = ok ? ph.t.y : h.t; prim = ok ? s + 1 : prim;
         }
-        hit_barycentrics(S, h, o, d);
+        brute_resolve(S, h, prim, o, d);
         return h;
     }
     ZD static bool any(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         bool occ = false;
         const_v4f_ptr q = as_constant(S.pairs);
 #pragma unroll 1
-        for (int s = 0; s < S.ntris; s += 2, q += 6) {
+        for (int s = 0; s < S.nquads; s += 2, q += 10) {
             PairHit ph = pair_test(q, o, d);
             occ |= ((ph.t.x > tmin) & (ph.t.x < tmax) & (ph.c.x >= 0.0f)) | ((ph.t.y > tmin) & (ph.t.y < tmax) & (ph.c.y >= 0.0f));
         }

@@ -21,14 +21,14 @@
 //     r0 {p0.xyz, uv0.x} r1 {p1.xyz, uv0.y} r2 {p2.xyz, uv1.x}
 //     r3 {n0.xyz, uv1.y} r4 {n1.xyz, uv2.x} r5 {n2.xyz, uv2.y}   n_i = inverse-transpose(M) * vn_i
 //     r6 {ng.xyz, bits(inst)}                                    ng = normalize(cross(p1-p0, p2-p0))
-//     r7 {area, bits(prim), 0, 0}                                read only on an emitter hit / by the ray-query kernels
+//     r7 {area, bits(prim), bits(rotation), 0}                                read only on an emitter hit / by the ray-query kernels
 // BVH4 node (64 B, four float4; child boxes quantised to 8 bits per plane on the node's own grid, rounded outwards):
 //   {origin.xyz, scale.x} {scale.y, scale.z, qlo.x[4], qlo.y[4]} {qlo.z[4], qhi.x[4], qhi.y[4], qhi.z[4]} {child[4]}
 //   plane = origin + scale * q (byte k of a q word belongs to child k); child = index << 3 | count:
 //   count == 0: index is a node; 1..4: first slot of a leaf of `count` triangles; 7: unused child.
 struct DScene {
     const float4 *isect;
-    const float4 *pairs;            // brute-force accel only: isect records of slots (2k, 2k+1) interleaved, 6 float4 per pair (accel.h)
+    const float4 *pairs;            // brute-force accel only: plane + four edge functions of primitives (2k, 2k+1) interleaved, 10 float4 per pair (accel.h)
     const float4 *shade;
     const float4 *nodes;
     const float *emission;          // ninst x 3   (heap slot 23333)
@@ -40,6 +40,7 @@ struct DScene {
     const float4 *light_tris; const int32_t *light_range; const float4 *emission4;   // emission4: ninst x {e.rgb, 0}
     int32_t light0_T;               // triangle count of light 0 (the whole table when light_count == 1)
     int32_t ntris, ninst, light_count, nnodes;
+    int32_t nquads, nquads2;        // brute-force accel: primitives of the pair walk (quads first, then single triangles) and the number of quads
     // environment light (envmap.py; heap slots 23330-23332): lat-long RGBA texture + importance tables
     const float4 *env_tex; const float *alias_prob; const int32_t *alias_idx; const float *env_pdf;
     int32_t env_count, env_h, env_w, map_w, map_h;

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -125,7 +126,7 @@ struct BvhBuilder {
 };
 
 // plane-form intersection record of one triangle, float64 -> float32 (accel.h, tri_test)
-static void plane_record(const h3 *p, float4 *out) {
+static void plane_record(const h3 *p, float4 *out, float4 *w_out = nullptr) {
     double p0[3] = {p[0].x, p[0].y, p[0].z};
     double e1[3] = {(double)p[1].x - p0[0], (double)p[1].y - p0[1], (double)p[1].z - p0[2]};
     double e2[3] = {(double)p[2].x - p0[0], (double)p[2].y - p0[1], (double)p[2].z - p0[2]};
@@ -136,6 +137,55 @@ static void plane_record(const h3 *p, float4 *out) {
     out[0] = make_float4((float)n[0], (float)n[1], (float)n[2], (float)(n[0] * p0[0] + n[1] * p0[1] + n[2] * p0[2]));
     out[1] = make_float4((float)nu[0], (float)nu[1], (float)nu[2], (float)-(nu[0] * p0[0] + nu[1] * p0[1] + nu[2] * p0[2]));
     out[2] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], (float)-(nv[0] * p0[0] + nv[1] * p0[1] + nv[2] * p0[2]));
+    if (w_out) {    // w = 1 - u - v as an edge function of its own (the third edge of a triangle that found no partner, find_quads)
+        const double du = -(nu[0] * p0[0] + nu[1] * p0[1] + nu[2] * p0[2]), dv = -(nv[0] * p0[0] + nv[1] * p0[1] + nv[2] * p0[2]);
+        *w_out = make_float4((float)-(nu[0] + nv[0]), (float)-(nu[1] + nv[1]), (float)-(nu[2] + nv[2]), (float)(1.0 - du - dv));
+    }
+}
+
+// Brute-force scenes: pairs of triangles that form a PLANAR CONVEX QUAD are tested as one primitive (accel.h, quad test):
+// one plane, one hit point, the four outer edge functions — 39 VALU for four triangles instead of 62.  Two triangles
+// merge when they share an edge (the same two world positions), lie in one plane (the apex of the second at most 5e-7 of
+// the quad's size off the plane of the first: a few float32 ulps of the corner coordinates themselves) on opposite sides of
+// that edge, and the quad is convex (the apex of each lies strictly inside the other's two outer edges).  For each input
+// triangle `rot` says which corner is the apex (= corner 0 of its slot's records: the diagonal is then the w = 0 edge of
+// both triangles and the outer edges are their u = 0 and v = 0 edges); `quads` lists the merged pairs (input indices).
+struct QuadPair { int a, b; };
+static void find_quads(const std::vector<h3> &pos, uint32_t ntris, std::vector<int> &rot, std::vector<QuadPair> &quads) {
+    rot.assign(ntris, 0); quads.clear();
+    struct EdgeKey { float k[6]; bool operator<(const EdgeKey &o) const { return memcmp(k, o.k, sizeof k) < 0; } };
+    auto key = [&](h3 a, h3 b) { EdgeKey e; const float A[3] = {a.x, a.y, a.z}, B[3] = {b.x, b.y, b.z};
+                                 const bool sw = memcmp(A, B, sizeof A) > 0; memcpy(e.k, sw ? B : A, 12); memcpy(e.k + 3, sw ? A : B, 12);
+                                 for (float &f : e.k) if (f == 0.0f) f = 0.0f;   /* -0 -> +0 */ return e; };
+    std::map<EdgeKey, std::vector<std::pair<int, int>>> edges;      // edge -> (triangle, corner opposite)
+    for (uint32_t t = 0; t < ntris; t++) for (int e = 0; e < 3; e++) edges[key(pos[3 * (size_t)t + (e + 1) % 3], pos[3 * (size_t)t + (e + 2) % 3])].push_back({(int)t, e});
+    std::vector<uint8_t> used(ntris, 0);
+    auto D = [](h3 v, double *o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; };
+    for (uint32_t t = 0; t < ntris; t++) {
+        if (used[t]) continue;
+        for (int e = 0; e < 3 && !used[t]; e++) {
+            for (const auto &cand : edges[key(pos[3 * (size_t)t + (e + 1) % 3], pos[3 * (size_t)t + (e + 2) % 3])]) {
+                const int t2 = cand.first, e2 = cand.second;
+                if (t2 == (int)t || used[t2]) continue;
+                double a0[3], s1[3], s2[3], b0[3];
+                D(pos[3 * (size_t)t + e], a0); D(pos[3 * (size_t)t + (e + 1) % 3], s1); D(pos[3 * (size_t)t + (e + 2) % 3], s2); D(pos[3 * (size_t)t2 + e2], b0);
+                double e1[3], e2v[3], r[3], n[3];
+                for (int k = 0; k < 3; k++) { e1[k] = s1[k] - a0[k]; e2v[k] = s2[k] - a0[k]; r[k] = b0[k] - a0[k]; }
+                n[0] = e1[1] * e2v[2] - e1[2] * e2v[1]; n[1] = e1[2] * e2v[0] - e1[0] * e2v[2]; n[2] = e1[0] * e2v[1] - e1[1] * e2v[0];
+                const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                if (!(nn > 0.0)) continue;
+                const double size = sqrt(std::max(std::max(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2v[0] * e2v[0] + e2v[1] * e2v[1] + e2v[2] * e2v[2]), r[0] * r[0] + r[1] * r[1] + r[2] * r[2]));
+                if (fabs(n[0] * r[0] + n[1] * r[1] + n[2] * r[2]) / sqrt(nn) > 5e-7 * size) continue;          // not in one plane
+                // barycentrics of b0 in (a0; s1, s2): u = weight of s1, v = weight of s2
+                const double u = ((e2v[1] * n[2] - e2v[2] * n[1]) * r[0] + (e2v[2] * n[0] - e2v[0] * n[2]) * r[1] + (e2v[0] * n[1] - e2v[1] * n[0]) * r[2]) / nn;
+                const double v = ((n[1] * e1[2] - n[2] * e1[1]) * r[0] + (n[2] * e1[0] - n[0] * e1[2]) * r[1] + (n[0] * e1[1] - n[1] * e1[0]) * r[2]) / nn;
+                if (!(u > 1e-6 && v > 1e-6 && 1.0 - u - v < -1e-6)) continue;                                   // not convex, or folded back
+                // and the other way round: a0 in (b0; its two shared corners) — symmetric by geometry, checked for degenerate cases
+                used[t] = used[t2] = 1; rot[t] = e; rot[t2] = e2; quads.push_back({(int)t, t2});
+                break;
+            }
+        }
+    }
 }
 
 // Builds the acceleration structure over world-space triangles (pos: ntris x 3 corners).
@@ -302,6 +352,7 @@ struct zdr_scene {
     std::vector<int32_t> inst_tri_begin;
     std::vector<float> emission;
     float4 *d_isect = nullptr, *d_pairs = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
+    uint32_t nquads = 0, nquads2 = 0;      // brute force: primitives of the pair walk, and how many of them are merged quads (find_quads)
     float *d_emission = nullptr;
     // flat light table (scene.h): one 80-byte entry per triangle of every emitting instance + {first entry, count} per light
     std::vector<float4> tri_geo;            // host copy, 4 float4 per INPUT triangle: p0, p1, p2, {ng, area} (lights may change)
@@ -427,13 +478,32 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
         if (rc) { delete s; return rc; }
     }
     s->accel_is_bvh = use_bvh ? 1 : 0;
+    // brute force: merge coplanar triangle pairs into quads; slots 2q, 2q + 1 = quad q, the single triangles follow
+    std::vector<int> rot(ntris, 0);
+    std::vector<QuadPair> quads;
+    if (!use_bvh) {
+        std::vector<h3> pos(3 * (size_t)ntris);
+        for (uint32_t t = 0; t < ntris; t++) for (int k = 0; k < 3; k++) pos[3 * (size_t)t + k] = rec[t].p[k];
+        if (!getenv("ZDR_NO_QUADS")) find_quads(pos, ntris, rot, quads);
+        std::vector<uint8_t> in_quad(ntris, 0);
+        uint32_t slot = 0;
+        for (const QuadPair &q : quads) { order[slot++] = q.a; order[slot++] = q.b; in_quad[q.a] = in_quad[q.b] = 1; }
+        for (uint32_t t = 0; t < ntris; t++) if (!in_quad[t]) order[slot++] = (int)t;
+        s->nquads2 = (uint32_t)quads.size(); s->nquads = ntris - s->nquads2;
+    }
 
     std::vector<float4> isect(3 * (size_t)ntris + 3, make_float4(0, 0, 0, 0)), shade(8 * (size_t)ntris);   // + one record: the BVH walk fetches four float4 behind a leaf's first triangle
     std::vector<int32_t> slot_of_tri(ntris);
+    std::vector<float4> wedge(ntris);       // third edge function of every slot (single triangles of the brute-force walk)
     for (uint32_t slot = 0; slot < ntris; slot++) {
-        const TriRec &r = rec[order[slot]];
+        TriRec r = rec[order[slot]];
         slot_of_tri[order[slot]] = (int32_t)slot;
-        plane_record(r.p, &isect[3 * (size_t)slot]);
+        const int ro = rot[order[slot]];     // the slot's corner 0 is input corner `ro` (cyclic: same triangle, same orientation)
+        if (ro) {
+            const TriRec in = r;
+            for (int k = 0; k < 3; k++) { r.p[k] = in.p[(k + ro) % 3]; r.n[k] = in.n[(k + ro) % 3]; r.uv[k][0] = in.uv[(k + ro) % 3][0]; r.uv[k][1] = in.uv[(k + ro) % 3][1]; }
+        }
+        plane_record(r.p, &isect[3 * (size_t)slot], &wedge[slot]);
         float4 *q = &shade[8 * (size_t)slot];
         q[0] = make_float4(r.p[0].x, r.p[0].y, r.p[0].z, r.uv[0][0]);
         q[1] = make_float4(r.p[1].x, r.p[1].y, r.p[1].z, r.uv[0][1]);
@@ -443,7 +513,8 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
         q[5] = make_float4(r.n[2].x, r.n[2].y, r.n[2].z, r.uv[2][1]);
         float fi, fp; memcpy(&fi, &r.inst, 4); memcpy(&fp, &r.prim, 4);
         q[6] = make_float4(r.ng.x, r.ng.y, r.ng.z, fi);
-        q[7] = make_float4(r.area, fp, 0.0f, 0.0f);
+        float fr; memcpy(&fr, &ro, 4);
+        q[7] = make_float4(r.area, fp, fr, 0.0f);          // .z: rotation of the slot's corners against the input triangle's
     }
     std::vector<int32_t> lights; int light_count = 0;
     light_list(s->emission, ninst, lights, light_count);
@@ -460,13 +531,17 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     auto up = [&](auto **dst, const void *src, size_t bytes) { if (e == hipSuccess) e = upload(dst, src, bytes, &s->device_bytes); };
     up(&s->d_isect, isect.data(), isect.size() * sizeof(float4));
     if (!use_bvh) {
-        // brute-force loops test two slots per trip with packed fp32 math: interleave the records
-        size_t npairs = ((size_t)ntris + 1) / 2;
-        std::vector<float> pr(24 * npairs, 0.0f);
-        for (uint32_t slot = 0; slot < ntris; slot++) {
-            const float *src = (const float *)&isect[3 * (size_t)slot];
-            float *dst = &pr[24 * (size_t)(slot / 2) + (slot & 1)];
-            for (int k = 0; k < 12; k++) dst[2 * k] = src[k];
+        // brute-force loops test two PRIMITIVES per trip with packed fp32 math, a primitive being a quad (slots 2q, 2q + 1)
+        // or a single triangle: plane N of the (first) triangle and four edge functions — u and v of both triangles of a quad,
+        // or u, v, w, w of a single triangle — five float4, interleaved for the two halves of a float2
+        size_t npairs = ((size_t)s->nquads + 1) / 2;
+        std::vector<float> pr(40 * npairs, 0.0f);
+        for (uint32_t q = 0; q < s->nquads; q++) {
+            const uint32_t a = q < s->nquads2 ? 2 * q : q + s->nquads2;
+            float4 src[5] = {isect[3 * (size_t)a], isect[3 * (size_t)a + 1], isect[3 * (size_t)a + 2], wedge[a], wedge[a]};
+            if (q < s->nquads2) { src[3] = isect[3 * (size_t)(a + 1) + 1]; src[4] = isect[3 * (size_t)(a + 1) + 2]; }
+            float *dst = &pr[40 * (size_t)(q / 2) + (q & 1)];
+            for (int k = 0; k < 20; k++) dst[2 * k] = ((const float *)src)[k];
         }
         up(&s->d_pairs, pr.data(), pr.size() * sizeof(float));
     }
@@ -484,6 +559,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     s->ds.light_insts = s->d_light_insts; s->ds.inst_tri_begin = s->d_inst_tri_begin; s->ds.slot_of_tri = s->d_slot_of_tri;
     s->ds.error_word = s->d_error;
     if (const char *e = getenv("ZDR_DEBUG_BVH_BUDGET")) s->ds.debug_bvh_budget = atoi(e);
+    s->ds.nquads = (int32_t)s->nquads; s->ds.nquads2 = (int32_t)s->nquads2;
     s->ds.ntris = (int32_t)ntris; s->ds.ninst = (int32_t)ninst; s->ds.light_count = light_count; s->ds.nnodes = (int32_t)s->bvh_nodes; s->ds.stack_entries = (int32_t)s->stack_entries;
     { int rc = upload_light_table(s, lights, light_count, nullptr); if (rc) { zdr_scene_destroy(s); return rc; } }
     *out = s;

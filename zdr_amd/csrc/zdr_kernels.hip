@@ -71,7 +71,7 @@ ZD int fetch_item(const RenderCfg &R, unsigned int *counters) {
 
 // candidate triangle pairs of this wave's camera rays (BruteAccel::closest_camera): the tile's mask, or every pair
 ZD unsigned long long camera_mask(const DScene &S, const KernelIO &io, const WorkItem &w) {
-    const int npairs = (S.ntris + 1) >> 1;
+    const int npairs = (S.nquads + 1) >> 1;
     const unsigned long long all = (npairs >= 64) ? ~0ull : ((1ull << npairs) - 1ull);
     return io.tile_masks ? io.tile_masks[w.tile] : all;
 }
@@ -110,7 +110,7 @@ ZD void flush_counters(const KernelIO &io, const Counters &cnt) {
 }
 
 // --------------------------------------------------------------------------- tile masks
-// One wave per 8x8 tile, lane = triangle pair: bit k of the tile's mask is set unless BOTH triangles
+// One wave per 8x8 tile, lane = pair of primitives of the brute-force walk: bit k of the tile's mask is set unless ALL triangles
 // of pair k lie entirely outside one side plane of the tile's camera frustum (or behind the camera).
 // The frustum is padded by one pixel: the tent filter (camera.py:20-31) moves a sample up to half a
 // pixel outside its pixel.  Conservative by construction — a set bit only costs a test.
@@ -128,10 +128,15 @@ __global__ __launch_bounds__(WAVE) void k_tile_masks(DScene S, RenderCfg R, unsi
     const f3 inside = (c00 + c11) + (c10 + c01);
 #pragma unroll
     for (int k = 0; k < 4; k++) if (dot(n[k], inside) < 0.0f) n[k] = n[k] * -1.0f;
-    const int npairs = (S.ntris + 1) >> 1;
+    const int npairs = (S.nquads + 1) >> 1;
     bool keep = false;
     if (lane < npairs) {
-        for (int t = 2 * lane; t < 2 * lane + 2 && t < S.ntris; t++) {
+        // the (up to four) triangles of primitives 2 lane and 2 lane + 1: quads cover slots 2q, 2q + 1, single triangles follow (accel.h)
+        const int q0 = 2 * lane, q1 = 2 * lane + 1;
+        const int b0 = q0 < S.nquads2 ? 2 * q0 : q0 + S.nquads2, n0 = q0 < S.nquads2 ? 2 : 1;
+        const int b1 = q1 < S.nquads2 ? 2 * q1 : q1 + S.nquads2, n1 = q1 >= S.nquads ? 0 : (q1 < S.nquads2 ? 2 : 1);
+        for (int i = 0; i < n0 + n1; i++) {
+            const int t = i < n0 ? b0 + i : b1 + (i - n0);
             const float4 *r = S.shade + 8 * (size_t)t;
             f3 v0 = xyz(r[0]) - co, v1 = xyz(r[1]) - co, v2 = xyz(r[2]) - co;
             float vm = fmaxf(fmaxf(length(v0), length(v1)), length(v2));
@@ -640,7 +645,13 @@ __global__ __launch_bounds__(WAVE) void k_trace(DScene S, const float4 *rays, ui
             int inst = -1, prim = -1;
             if (h.slot >= 0) { inst = __float_as_int(S.shade[8 * (size_t)h.slot + 6].w); prim = __float_as_int(S.shade[8 * (size_t)h.slot + 7].y); }
             out_i[2 * (size_t)i] = inst; out_i[2 * (size_t)i + 1] = prim;
-            out_f[3 * (size_t)i] = h.u; out_f[3 * (size_t)i + 1] = h.v; out_f[3 * (size_t)i + 2] = (h.slot >= 0) ? h.t : b.w;
+            float hu = h.u, hv = h.v;
+            if (h.slot >= 0) {   // the slot's corners may be a rotation of the input triangle's (quads, zdr_api.cpp): report the barycentrics of the INPUT corners 1 and 2
+                const int ro = __float_as_int(S.shade[8 * (size_t)h.slot + 7].z);
+                const float hw = 1.0f - h.u - h.v;
+                if (ro == 1) { hu = hw; hv = h.u; } else if (ro == 2) { hu = h.v; hv = hw; }
+            }
+            out_f[3 * (size_t)i] = hu; out_f[3 * (size_t)i + 1] = hv; out_f[3 * (size_t)i + 2] = (h.slot >= 0) ? h.t : b.w;
         }
     }
 }

@@ -174,7 +174,11 @@ int zdr_path_dump(zdr_scene *scene, const zdr_render_params *params, const float
  * without touching a GPU, so that the CPU test-suite can run an emulation of the device traversal
  * on the very data the kernels read (tests/test_bvh_emulation.py).  tri_xyz: ntris x 9 world-space
  * corners.  nodes_out: nodes_cap x 16 floats (BVH4 node = 64 bytes, layout in csrc/scene.h);
- * order_out[slot] = input triangle; isect_out: ntris x 12 floats (plane-form records, slot order). */
+ * order_out[slot] = input triangle; isect_out: ntris x 12 floats (plane-form records, slot order).
+ * Brute force (ZDR_ACCEL_BRUTE, or AUTO with <= 64 triangles): there are no nodes; *nnodes receives the number Q of
+ * planar convex quads the walk merged out of coplanar triangle pairs — slots 2q and 2q + 1 for q < Q, the other
+ * triangles after them — and the records of a quad's two triangles start at the corner OPPOSITE the shared edge
+ * (tests/test_brute_quads.py). */
 int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int accel, float *nodes_out, uint32_t nodes_cap,
                           uint32_t *nnodes, uint32_t *stack_entries, int32_t *order_out, float *isect_out);
 

@@ -159,14 +159,15 @@ static void find_quads(const std::vector<h3> &pos, uint32_t ntris, std::vector<i
                                  for (float &f : e.k) if (f == 0.0f) f = 0.0f;   /* -0 -> +0 */ return e; };
     std::map<EdgeKey, std::vector<std::pair<int, int>>> edges;      // edge -> (triangle, corner opposite)
     for (uint32_t t = 0; t < ntris; t++) for (int e = 0; e < 3; e++) edges[key(pos[3 * (size_t)t + (e + 1) % 3], pos[3 * (size_t)t + (e + 2) % 3])].push_back({(int)t, e});
-    std::vector<uint8_t> used(ntris, 0);
     auto D = [](h3 v, double *o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; };
+    // which pairs COULD merge (t with corner e as its apex, t2 with corner e2)
+    struct Cand { int t2, e, e2; };
+    std::vector<std::vector<Cand>> adj(ntris);
     for (uint32_t t = 0; t < ntris; t++) {
-        if (used[t]) continue;
-        for (int e = 0; e < 3 && !used[t]; e++) {
+        for (int e = 0; e < 3; e++) {
             for (const auto &cand : edges[key(pos[3 * (size_t)t + (e + 1) % 3], pos[3 * (size_t)t + (e + 2) % 3])]) {
                 const int t2 = cand.first, e2 = cand.second;
-                if (t2 == (int)t || used[t2]) continue;
+                if (t2 == (int)t) continue;
                 double a0[3], s1[3], s2[3], b0[3];
                 D(pos[3 * (size_t)t + e], a0); D(pos[3 * (size_t)t + (e + 1) % 3], s1); D(pos[3 * (size_t)t + (e + 2) % 3], s2); D(pos[3 * (size_t)t2 + e2], b0);
                 double e1[3], e2v[3], r[3], n[3];
@@ -180,12 +181,44 @@ static void find_quads(const std::vector<h3> &pos, uint32_t ntris, std::vector<i
                 const double u = ((e2v[1] * n[2] - e2v[2] * n[1]) * r[0] + (e2v[2] * n[0] - e2v[0] * n[2]) * r[1] + (e2v[0] * n[1] - e2v[1] * n[0]) * r[2]) / nn;
                 const double v = ((n[1] * e1[2] - n[2] * e1[1]) * r[0] + (n[2] * e1[0] - n[0] * e1[2]) * r[1] + (n[0] * e1[1] - n[1] * e1[0]) * r[2]) / nn;
                 if (!(u > 1e-6 && v > 1e-6 && 1.0 - u - v < -1e-6)) continue;                                   // not convex, or folded back
-                // and the other way round: a0 in (b0; its two shared corners) — symmetric by geometry, checked for degenerate cases
-                used[t] = used[t2] = 1; rot[t] = e; rot[t2] = e2; quads.push_back({(int)t, t2});
-                break;
+                // (the corners at the two apices are corners of a triangle, hence convex: nothing else to check)
+                adj[t].push_back({t2, e, e2});
             }
         }
     }
+    // greedy matching, the triangles with the fewest possible partners first (each takes its partner with the fewest): a strip
+    // of quads pairs up along its own diagonals instead of across its cells
+    std::vector<int> by_degree(ntris);
+    for (uint32_t t = 0; t < ntris; t++) by_degree[t] = (int)t;
+    std::stable_sort(by_degree.begin(), by_degree.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+    std::vector<uint8_t> used(ntris, 0);
+    for (int t : by_degree) {
+        if (used[t]) continue;
+        const Cand *best = nullptr;
+        for (const Cand &c : adj[t]) {
+            if (used[c.t2]) continue;
+            bool mutual = false;                                   // t2 must see t over the same edge (both tolerances hold)
+            for (const Cand &d : adj[c.t2]) mutual = mutual || (d.t2 == t && d.e == c.e2 && d.e2 == c.e);
+            if (mutual && (!best || adj[c.t2].size() < adj[best->t2].size())) best = &c;
+        }
+        if (!best) continue;
+        used[t] = used[best->t2] = 1; rot[t] = best->e; rot[best->t2] = best->e2;
+        quads.push_back({std::min(t, best->t2), std::max(t, best->t2)});
+    }
+    std::sort(quads.begin(), quads.end(), [](const QuadPair &x, const QuadPair &y) { return x.a < y.a; });
+}
+
+// Slot order of the brute-force walk: the two triangles of quad q in slots 2q and 2q + 1, the single triangles after them.
+static uint32_t brute_slot_order(const std::vector<h3> &pos, uint32_t ntris, std::vector<int> &order, std::vector<int> &rot) {
+    std::vector<QuadPair> quads;
+    rot.assign(ntris, 0);
+    if (!getenv("ZDR_NO_QUADS")) find_quads(pos, ntris, rot, quads);
+    std::vector<uint8_t> in_quad(ntris, 0);
+    order.resize(ntris);
+    uint32_t slot = 0;
+    for (const QuadPair &q : quads) { order[slot++] = q.a; order[slot++] = q.b; in_quad[q.a] = in_quad[q.b] = 1; }
+    for (uint32_t t = 0; t < ntris; t++) if (!in_quad[t]) order[slot++] = (int)t;
+    return (uint32_t)quads.size();
 }
 
 // Builds the acceleration structure over world-space triangles (pos: ntris x 3 corners).
@@ -480,16 +513,10 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     s->accel_is_bvh = use_bvh ? 1 : 0;
     // brute force: merge coplanar triangle pairs into quads; slots 2q, 2q + 1 = quad q, the single triangles follow
     std::vector<int> rot(ntris, 0);
-    std::vector<QuadPair> quads;
     if (!use_bvh) {
         std::vector<h3> pos(3 * (size_t)ntris);
         for (uint32_t t = 0; t < ntris; t++) for (int k = 0; k < 3; k++) pos[3 * (size_t)t + k] = rec[t].p[k];
-        if (!getenv("ZDR_NO_QUADS")) find_quads(pos, ntris, rot, quads);
-        std::vector<uint8_t> in_quad(ntris, 0);
-        uint32_t slot = 0;
-        for (const QuadPair &q : quads) { order[slot++] = q.a; order[slot++] = q.b; in_quad[q.a] = in_quad[q.b] = 1; }
-        for (uint32_t t = 0; t < ntris; t++) if (!in_quad[t]) order[slot++] = (int)t;
-        s->nquads2 = (uint32_t)quads.size(); s->nquads = ntris - s->nquads2;
+        s->nquads2 = brute_slot_order(pos, ntris, order, rot); s->nquads = ntris - s->nquads2;
     }
 
     std::vector<float4> isect(3 * (size_t)ntris + 3, make_float4(0, 0, 0, 0)), shade(8 * (size_t)ntris);   // + one record: the BVH walk fetches four float4 behind a leaf's first triangle
@@ -576,13 +603,19 @@ extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int a
     std::vector<int> order; std::vector<float4> nodes; uint32_t nn = 0, depth = 0, se = 8;
     bool use_bvh = (accel == ZDR_ACCEL_BVH) || (accel == ZDR_ACCEL_AUTO && ntris > 64);
     int rc = build_accel(pos, ntris, use_bvh, order, nodes, nn, depth, se); if (rc) return rc;
+    std::vector<int> rot(ntris, 0);
+    if (!use_bvh) nn = brute_slot_order(pos, ntris, order, rot);      // brute force: *nnodes = merged quads (slots 2q, 2q + 1), no nodes
     *nnodes = nn;
     if (stack_entries) *stack_entries = se;
-    if (nn > nodes_cap) return fail(ZDR_E_NOMEM, "nodes_out too small");
-    if (nn) memcpy(nodes_out, nodes.data(), (size_t)nn * 4 * sizeof(float4));
+    if (use_bvh) {
+        if (nn > nodes_cap) return fail(ZDR_E_NOMEM, "nodes_out too small");
+        if (nn) memcpy(nodes_out, nodes.data(), (size_t)nn * 4 * sizeof(float4));
+    }
     for (uint32_t slot = 0; slot < ntris; slot++) {
         order_out[slot] = order[slot];
-        float4 q[3]; plane_record(&pos[3 * (size_t)order[slot]], q);
+        const int ro = rot[order[slot]];
+        h3 c[3]; for (int k = 0; k < 3; k++) c[k] = pos[3 * (size_t)order[slot] + (k + ro) % 3];
+        float4 q[3]; plane_record(c, q);
         memcpy(isect_out + 12 * (size_t)slot, q, sizeof q);
     }
     return ZDR_OK;

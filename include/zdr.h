@@ -57,9 +57,11 @@ typedef struct {
     zdr_camera camera;
     int32_t tex_h, tex_w;              /* material tensor is (tex_h, tex_w, 4) float32 */
     /* Interleaved pixel-tile shard (BASELINE configs[3] "pixel-tiled across 8 GPUs"): the rectangle is cut
-     * into 8x8 tiles numbered row-major from its own corner, and this call renders the tiles whose number is
-     * congruent to tile_shard_index modulo tile_shard_count — one launch per rank, every rank sees every part of the
-     * image (load balance).  tile_shard_count <= 1: the whole rectangle. */
+     * into 8x8 tiles numbered row by row from its own corner, row r starting at column r (mod the row length) — so that
+     * the tiles of one shard run along diagonals, not down the columns of the image — and this call renders the tiles
+     * whose number is congruent to tile_shard_index modulo tile_shard_count: one launch per rank, every rank sees every
+     * part of the image (load balance).  The shards of one count partition the rectangle.  tile_shard_count <= 1: the
+     * whole rectangle. */
     int32_t tile_shard_index, tile_shard_count;
     /* Form of the PRB adjoint (backward of the path integrator only).  ZDR_PRB_EXPECTATION (0, default): the derivative of
      * the forward's expectation, which is what finite differences of render() measure (BASELINE.json's gradient bar) —

@@ -125,7 +125,7 @@ def test_shard_unions(mat_a):
 @pytest.mark.parametrize("integrator,accel", [("path", "brute"), ("path", "bvh"), ("direct", "brute")])
 @pytest.mark.parametrize("count", [2, 3, 8])
 def test_interleaved_tile_shards_union(integrator, accel, count, mat_a):
-    """BASELINE configs[3]: pixel tiles dealt round-robin to `count` ranks (zdr_render_params.tile_shard_*), one launch
+    """BASELINE configs[3]: pixel tiles dealt round-robin to `count` ranks along diagonals (zdr_render_params.tile_shard_*), one launch
     each.  A pixel's samples do not depend on who renders it: the union of the shards is the unsharded image — bit for bit
     here, where shard and whole frame cut the sample range into the same chunks (at other sizes up to the re-association
     of the per-pixel sum, tools/shard_balance.py: 7e-7 at 1024^2 spp 1024) — the gradients add up to the unsharded gradient,
@@ -142,7 +142,8 @@ def test_interleaved_tile_shards_union(integrator, accel, count, mat_a):
         owner += mine.int()
         parts = torch.where(mine[..., None], one, parts)
         ty, tx = torch.meshgrid(torch.arange(H, device="cuda") // 8, torch.arange(W, device="cuda") // 8, indexing="ij")
-        assert torch.equal(mine, (ty * ((W + 7) // 8) + tx) % count == r)
+        tiles_x = (W + 7) // 8                                    # zdr.h: row ty is numbered from column ty on -> a shard's tiles run along diagonals
+        assert torch.equal(mine, (ty * tiles_x + (tx - ty) % tiles_x) % count == r)
     assert (owner == 1).all() and torch.equal(parts, full)
     cot = torch.from_numpy(np.random.default_rng(2).uniform(0.5, 1.5, (H, W, 4)).astype(np.float32)).cuda()
     g_full = torch.zeros_like(m); g_parts = torch.zeros_like(m)

@@ -24,7 +24,8 @@ struct RenderCfg {
     uint32_t sample_begin, sample_end;
     uint32_t chunk;                   // samples per wave: chunk c covers [begin + c*chunk, ...)
     int32_t nchunks, tiles_x, tiles_y;
-    int32_t shard_index, shard_count, ntiles;   // interleaved tile shard: tiles index, index + count, ... ; ntiles = how many that is
+    int32_t shard_index, shard_count, ntiles;   // interleaved tile shard: tile numbers index, index + count, ... ; ntiles = how many that is
+    int32_t shard_skew;                         // row r of the tile grid is numbered starting at column r * skew (1 when sharded: diagonals; 0 otherwise)
     int32_t use_tent, max_depth, rr_depth;
     int32_t tex_h, tex_w;
     int32_t prb_detached;             // backward, path: roulette factors and MIS weights held constant (zdr.h, ZDR_PRB_DETACHED)

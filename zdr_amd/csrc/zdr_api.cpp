@@ -759,6 +759,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     R.prb_detached = p->prb_mode == ZDR_PRB_DETACHED;
     R.shard_count = p->tile_shard_count > 1 ? p->tile_shard_count : 1;
     R.shard_index = p->tile_shard_count > 1 ? p->tile_shard_index : 0;
+    R.shard_skew = R.shard_count > 1 ? 1 : 0;
     const long all_tiles = (long)R.tiles_x * R.tiles_y;
     R.ntiles = (int32_t)(all_tiles > R.shard_index ? (all_tiles - R.shard_index + R.shard_count - 1) / R.shard_count : 0);
     long tiles = R.ntiles;

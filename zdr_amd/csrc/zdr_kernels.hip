@@ -26,9 +26,11 @@ ZD WorkItem decode_item(const RenderCfg &R, int logical) {
     w.valid = logical >= 0 && logical < nblocks;
     const int tl = w.valid ? logical / R.nchunks : 0;
     w.chunk = w.valid ? logical - tl * R.nchunks : 0;
-    const int tile = tl * R.shard_count + R.shard_index;     // interleaved tile shard (zdr.h)
-    w.tile = tile; w.tile_local = tl;
-    const int ty = tile / R.tiles_x, tx = tile - ty * R.tiles_x;
+    const int number = tl * R.shard_count + R.shard_index;   // interleaved tile shard (zdr.h): tile numbers index, index + count, ...
+    const int ty = number / R.tiles_x;
+    int tx = number - ty * R.tiles_x + ty * R.shard_skew;    // row ty is numbered from column ty * skew on: a shard's tiles run along diagonals
+    tx -= (tx / R.tiles_x) * R.tiles_x;
+    w.tile = ty * R.tiles_x + tx; w.tile_local = tl;         // .tile: position in the tile grid (tile masks), .tile_local: position in the shard's workspace
     const int lane = threadIdx.x;
     w.x = R.x0 + tx * 8 + (lane & 7);
     w.y = R.y0 + ty * 8 + (lane >> 3);
@@ -527,7 +529,10 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
     int x = R.x0 + blockIdx.x * blockDim.x + threadIdx.x, y = R.y0 + blockIdx.y;
     if (x >= R.x1 || y >= R.y1) return;
     const size_t pix = (size_t)x + (size_t)y * R.width;
-    const int lx = x - R.x0, ly = y - R.y0, tile = (ly >> 3) * R.tiles_x + (lx >> 3);
+    const int lx = x - R.x0, ly = y - R.y0, ty = ly >> 3;
+    int c = (lx >> 3) - (ty * R.shard_skew) % R.tiles_x;     // the tile's number in its row (decode_item)
+    if (c < 0) c += R.tiles_x;
+    const int tile = ty * R.tiles_x + c;
     if (tile % R.shard_count != R.shard_index) return;      // another shard's pixel: untouched
     const size_t slot = (size_t)(tile / R.shard_count) * 64 + (size_t)((ly & 7) * 8 + (lx & 7));
     f3 s = mk3(0.0f);

@@ -6,7 +6,7 @@ and of the material gradient — an all_reduce over RCCL/xGMI (``b
 ROCm).  Payloads are small (16 MiB each at 1024^2), far below what the render itself costs.
 
 Shard modes
-  "tiles"    pixel tiles: the 8x8 tiles of the image dealt round-robin to the ranks, ONE launch per rank
+  "tiles"    pixel tiles: the 8x8 tiles of the image dealt round-robin to the ranks along diagonals, ONE launch per rank
              (zdr_render_params.tile_shard_*); every pixel receives the same samples whoever renders it: the union equals the
              unsharded image bit for bit when both cut the sample range into the same chunks, otherwise up to float
              re-association of the per-pixel sum.  BASELINE configs[3].

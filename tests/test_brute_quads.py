@@ -80,3 +80,56 @@ def test_one_primitive_per_triangle_when_switched_off(monkeypatch):
     monkeypatch.setenv("ZDR_NO_QUADS", "1")
     nq, order, _ = build(quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)))
     assert nq == 0 and order.tolist() == [0, 1]
+
+
+def emulate_quad_walk(nq, order, isect, rays):
+    """float32 NumPy mirror of BruteAccel::closest + brute_resolve (csrc/accel.h): primitives = quads (slots 2q, 2q + 1:
+    plane of the first triangle, u and v of both) then single triangles (u, v, w, w); nearest primitive, then the
+    triangle of the quad by the sign of the first one's w.  Returns (input triangle or -1, t)."""
+    f = np.float32
+    n = order.shape[0]
+    nprim = n - nq
+    o, d, tmin, tmax = rays[:, 0:3], rays[:, 4:7], rays[:, 3], rays[:, 7]
+    best_t = tmax.copy(); best_p = np.full(rays.shape[0], -1)
+    def edge(rec, p):
+        return (p @ rec[:3] + rec[3]).astype(f)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for q in range(nprim):
+            a = 2 * q if q < nq else q + nq
+            N, U, V = isect[a, 0:4], isect[a, 4:8], isect[a, 8:12]
+            t = ((N[3] - (o @ N[:3]).astype(f)) / (d @ N[:3]).astype(f)).astype(f)
+            p = (o + d * t[:, None]).astype(f)
+            u, v = edge(U, p), edge(V, p)
+            if q < nq:
+                e3, e4 = edge(isect[a + 1, 4:8], p), edge(isect[a + 1, 8:12], p)
+            else:
+                e3 = e4 = (f(1.0) - (u + v)).astype(f)
+            c = np.minimum(np.minimum(u, v), np.minimum(e3, e4))
+            ok = (t > tmin) & (t < best_t) & (c >= 0)
+            best_t = np.where(ok, t, best_t); best_p = np.where(ok, q, best_p)
+    tri = np.full(rays.shape[0], -1)
+    hit = best_p >= 0
+    slot = np.where(best_p < nq, 2 * best_p, best_p + nq)
+    p = (o + d * best_t[:, None]).astype(f)
+    for i in np.nonzero(hit)[0]:
+        s = slot[i]
+        if best_p[i] < nq:
+            u, v = p[i] @ isect[s, 4:7] + isect[s, 7], p[i] @ isect[s, 8:11] + isect[s, 11]
+            if 1.0 - (u + v) < 0: s += 1
+        tri[i] = order[s]
+    return tri, best_t
+
+
+def test_quad_walk_emulation_matches_the_oracle(cbox_arrays, cbox_oracle):
+    """The walk over quads finds the triangles the oracle's per-triangle brute force finds (same tolerance as the GPU test)."""
+    from gpu_util import random_rays
+    A = cbox_arrays
+    nq, order, isect = build(A.verts[A.tris][:, :, :3])
+    rays = random_rays(20000, (-3, 0, -5.5), (2.5, 5.2, 6), seed=9)
+    tri, t = emulate_quad_walk(nq, order, isect, rays)
+    rip, rbt = cbox_oracle.trace_closest(rays)
+    ref = np.where(rip[:, 0] >= 0, A.inst_tri_begin[np.maximum(rip[:, 0], 0)] + rip[:, 1], -1)
+    assert (tri != ref).mean() < 2e-4
+    both = (tri >= 0) & (tri == ref)
+    terr = np.abs(t[both] - rbt[both, 2]) / (1e-5 * np.abs(rbt[both, 2]) + 5e-6)
+    assert both.mean() > 0.3 and (terr > 1).mean() < 2e-4 and terr.max() < 50

@@ -1,0 +1,36 @@
+"""Run by tests/test_host_sanitizers.py under LD_PRELOAD=libclang_rt.asan: the HOST side of libzdr_hip.so that needs no GPU —
+the BVH builder, the quad merge, the plane records (zdr_debug_build_accel) and the argument checks of the entry points."""
+import sys, os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import ctypes as C
+import numpy as np
+from zdr_amd import _native, build as hip_build
+_native.LIB_PATH = sys.argv[1]
+hip_build.stale = lambda: False
+from conftest import cbox_models
+from gpu_util import multi_light_arrays, terrain_arrays
+from zdr_amd import geometry, procedural
+import test_bvh_emulation as E
+import test_brute_quads as Q
+L = _native.lib()
+A = geometry.assemble(cbox_models())
+for accel in (_native.ACCEL_BRUTE, _native.ACCEL_BVH):
+    for arrays in (A, multi_light_arrays(), terrain_arrays(n=24)):
+        nodes, order, isect = E.build(arrays, accel)
+        print(accel, arrays.tris.shape[0], len(nodes), int(order.sum()))
+big = procedural.tessellated_cbox(cbox_models(), n=24)
+nodes, order, isect = E.build(big, _native.ACCEL_BVH); print("tess", big.tris.shape[0], len(nodes))
+nodes, order, isect = E.build(big, _native.ACCEL_BRUTE); print("tess brute quads", big.tris.shape[0])
+print("quads", Q.build(A.verts[A.tris][:, :, :3])[0])
+Q.test_only_planar_convex_pairs_merge()
+# degenerate input: zero-area and NaN triangles must not crash the builders
+bad = np.zeros((6, 9), np.float32); bad[1] = np.nan; bad[2, :3] = 1; bad[3] = [0, 0, 0, 1, 0, 0, 0, 1, 0]; bad[4] = [0, 0, 0, 0, 1, 0, 1, 0, 0]; bad[5] = bad[3]
+for accel in (_native.ACCEL_BRUTE, _native.ACCEL_BVH):
+    nq, se = C.c_uint32(0), C.c_uint32(0)
+    order = np.zeros(6, np.int32); isect = np.zeros((6, 12), np.float32); nodes = np.zeros((16, 16), np.float32)
+    rc = L.zdr_debug_build_accel(bad.ctypes.data, 6, accel, nodes.ctypes.data, 16, C.byref(nq), C.byref(se), order.ctypes.data, isect.ctypes.data)
+    print("degenerate", accel, rc, sorted(order.tolist()))
+# argument checks that return before any HIP call
+h = C.c_void_p()
+print("create(null)", L.zdr_scene_create(None, 0, None, 0, None, None, None, 0, 0, 0, C.byref(h)), L.zdr_last_error().decode()[:40])
+print("destroy(null)", L.zdr_scene_destroy(None), "check(null)", L.zdr_scene_check(None, None))
+print("ok")

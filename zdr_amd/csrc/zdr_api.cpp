@@ -62,6 +62,9 @@ struct BvhBuilder {
     static void grow(float *lo, float *hi, const float *plo, const float *phi) {
         for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], plo[k]); hi[k] = std::max(hi[k], phi[k]); }
     }
+    static int bin_of(float f) {     // float -> bin, clamped; a NaN centroid (garbage input) lands in bin 0 instead of an undefined conversion
+        return (f >= 0.0f) ? ((f < (float)kBins) ? (int)f : kBins - 1) : 0;
+    }
     static float area(const float *lo, const float *hi) {
         float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         return 2.0f * (dx * dy + dy * dz + dz * dx);
@@ -89,7 +92,7 @@ struct BvhBuilder {
                 for (int k = 0; k < kBins; k++) { bc[k] = 0; for (int j = 0; j < 3; j++) { blo[k][j] = 3e38f; bhi[k][j] = -3e38f; } }
                 float scale = (float)kBins / ext;
                 for (int i = b; i < e; i++) {
-                    int k = std::min(kBins - 1, std::max(0, (int)((prims[i].c[ax] - clo[ax]) * scale)));
+                    int k = bin_of((prims[i].c[ax] - clo[ax]) * scale);
                     bc[k]++; grow(blo[k], bhi[k], prims[i].lo, prims[i].hi);
                 }
                 float rlo[kBins][3], rhi[kBins][3]; int rc[kBins];
@@ -106,7 +109,7 @@ struct BvhBuilder {
             if (best_axis >= 0) {
                 float ext = chi[best_axis] - clo[best_axis], scale = (float)kBins / ext;
                 auto it = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim &p) {
-                    int k = std::min(kBins - 1, std::max(0, (int)((p.c[best_axis] - clo[best_axis]) * scale)));
+                    int k = bin_of((p.c[best_axis] - clo[best_axis]) * scale);
                     return k <= best_bin; });
                 mid = (int)(it - prims.begin());
             }

@@ -32,5 +32,10 @@ for accel in (_native.ACCEL_BRUTE, _native.ACCEL_BVH):
 # argument checks that return before any HIP call
 h = C.c_void_p()
 print("create(null)", L.zdr_scene_create(None, 0, None, 0, None, None, None, 0, 0, 0, C.byref(h)), L.zdr_last_error().decode()[:40])
+v = np.zeros((3, 8), np.float32); t = np.array([[0, 1, 2]], np.int32); e = np.zeros((1, 3), np.float32)
+for begin, tri, what in (([1, 1], t, "begin"), ([0, 2], t, "span"), ([0, 1], np.array([[0, 1, 7]], np.int32), "index"), ([0, 1], np.array([[0, -1, 2]], np.int32), "negative")):
+    b = np.array(begin, np.int32)
+    rc = L.zdr_scene_create(v.ctypes.data, 3, tri.ctypes.data, 1, b.ctypes.data, None, e.ctypes.data, 1, 0, 0, C.byref(h))
+    print("create", what, rc, L.zdr_last_error().decode()[:50]); assert rc != 0
 print("destroy(null)", L.zdr_scene_destroy(None), "check(null)", L.zdr_scene_check(None, None))
 print("ok")

@@ -90,3 +90,27 @@ def test_constant_image_round_trips_through_rle(tmp_path):
     p = str(tmp_path / "c.exr")
     exr.write_exr(p, np.full((8, 64, 3), 2.5, np.float32), compression=exr.RLE)
     assert np.array_equal(exr.read_exr(p), np.full((8, 64, 3), 2.5, np.float32))
+
+
+def test_truncated_and_corrupt_files_raise_a_clean_error(tmp_path):
+    """A damaged file must end in ValueError (or NotImplementedError when the damage reads as an unsupported feature) —
+    never in an IndexError / struct.error from the middle of the parser, never in a huge allocation."""
+    img = np.random.default_rng(0).uniform(0, 2, (9, 13, 3)).astype(np.float32)
+    p = str(tmp_path / "a.exr")
+    rng = np.random.default_rng(1)
+    for comp in (exr.NO_COMPRESSION, exr.RLE, exr.ZIPS, exr.ZIP):
+        exr.write_exr(p, img, compression=comp)
+        good = open(p, "rb").read()
+        for trial in range(150):
+            bad = bytearray(good)
+            if trial % 3 == 0:
+                bad = bad[:rng.integers(1, len(bad))]
+            else:
+                for _ in range(rng.integers(1, 4)):
+                    bad[rng.integers(0, len(bad))] = rng.integers(0, 256)
+            open(p, "wb").write(bytes(bad))
+            try:
+                out = exr.read_exr(p)
+                assert out.ndim == 3 and out.shape[0] * out.shape[1] <= (1 << 28)
+            except (ValueError, NotImplementedError):
+                pass

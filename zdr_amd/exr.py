@@ -94,7 +94,16 @@ def _zip(raw: bytes, rle: bool = False) -> bytes:
 
 
 def read_exr(path: str) -> np.ndarray:
-    """-> (H, W, C) float32; channels ordered R, G, B(, A) when the file has them, else alphabetically."""
+    """-> (H, W, C) float32; channels ordered R, G, B(, A) when the file has them, else alphabetically.
+    A file that is truncated or corrupt raises ValueError (an unsupported feature NotImplementedError)."""
+    import zlib
+    try:
+        return _read_exr(path)
+    except (struct.error, KeyError, IndexError, zlib.error, OverflowError, MemoryError) as e:
+        raise ValueError(f"{path}: truncated or corrupt OpenEXR file ({type(e).__name__}: {e})") from e
+
+
+def _read_exr(path: str) -> np.ndarray:
     buf = open(path, "rb").read()
     magic, version = struct.unpack_from("<ii", buf, 0)
     if magic != MAGIC:
@@ -122,6 +131,8 @@ def read_exr(path: str) -> np.ndarray:
         raise NotImplementedError(f"{path}: {_NAMES.get(comp, comp)} compression is not supported (NONE, RLE, ZIPS and ZIP are); re-save the file, e.g. `oiiotool in.exr --compression zip -o out.exr`")
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     W, H = x1 - x0 + 1, y1 - y0 + 1
+    if W < 1 or H < 1 or W * H > (1 << 28) or not channels:
+        raise ValueError(f"{path}: implausible data window {W} x {H} or no channels")
     nlines = _LINES[comp]
     nchunks = (H + nlines - 1) // nlines
     offsets = struct.unpack_from(f"<{nchunks}Q", buf, pos)
@@ -130,6 +141,8 @@ def read_exr(path: str) -> np.ndarray:
     for off in offsets:
         y, size = struct.unpack_from("<ii", buf, off)
         rows = min(nlines, y1 - y + 1)
+        if y < y0 or rows < 1 or size < 0 or off + 8 + size > len(buf):
+            raise ValueError(f"{path}: corrupt scan-line block at offset {off}")
         data = buf[off + 8:off + 8 + size]
         raw = data if comp == NO_COMPRESSION else _unzip(data, rows * line_bytes, rle=(comp == RLE))
         q = 0

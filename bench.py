@@ -9,7 +9,7 @@ One step = scene.render(material, res, spp, seed=random) followed by I.sum().bac
   --gpus N > 1        BASELINE configs[3]: cbox path 1024x1024 spp 1024, ONE render pixel-tiled over the N ranks
                       (8x8 tiles dealt round-robin, one launch per rank and pass) and one RCCL all_reduce of the image
                       and of the gradient per step: fixed total work, "scaling": "strong"
-  --config c5         BASELINE configs[4]: 1,004,670-triangle tessellated cbox (BVH), path + PRB 1024x1024 spp 256,
+  --config c5         BASELINE configs[4]: 1,004,672-triangle tessellated cbox (BVH), path + PRB 1024x1024 spp 256,
                       on 1 or N GPUs (tiled like c4)
 
 Launch: `python bench.py --gpus N ...` starts its N ranks itself (torch.distributed.run as a child process, before
@@ -218,7 +218,7 @@ def main():
         bwd_kernel_ms = bwd_ms / max(launches["bwd"], 1)    # dominant kernel = the PRB backward kernel, average launch
         achieved = a_bwd * (n_rank / max(launches["bwd"], 1)) / (bwd_kernel_ms * 1e-3) / 1e9
         accel = scene.info()["accel"]
-        names = {"c2": "cbox direct", "c3": "cbox path", "c4": "cbox path", "c5": "1,004,670-triangle tessellated cbox, path"}
+        names = {"c2": "cbox direct", "c3": "cbox path", "c4": "cbox path", "c5": "1,004,672-triangle tessellated cbox, path"}
         out = {
             "metric": "Msamples/s fwd+PRB-bwd" + (", cbox 512x512 spp=256" if (cfg, W, spp) == ("c3", 512, 256) else f", {names[cfg]} {W}x{W} spp={spp}"),
             "value": round(2 * n_per_pass * args.steps * (world if weak else 1) / dt / 1e6, 2),

@@ -113,6 +113,31 @@ ZD PairHit pair_test(const_v4f_ptr q, f3 o, f3 d) {
     return h;
 }
 
+// Two PARALLELOGRAMS (the host puts their pairs first, S.nppairs of them): with p = a0 + u e1 + v e2 the outer edges of the
+// second triangle are u <= 1 and v <= 1, so its two edge functions are 1 - u and 1 - v of the first — six float4 per pair
+// {N} {U} {V} interleaved (S.ppairs), 33 VALU instead of 39 (11 of the Cornell box's 15 quads are parallelograms).
+ZD PairHit pair_test_par(const_v4f_ptr q, f3 o, f3 d) {
+    v4f q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+    v2f dx = splat(d.x), dy = splat(d.y), dz = splat(d.z), ox = splat(o.x), oy = splat(o.y), oz = splat(o.z);
+    v2f nd = pfma(q1.xy, dz, pfma(q0.zw, dy, q0.xy * dx));
+    v2f no = pfma(q1.xy, oz, pfma(q0.zw, oy, q0.xy * ox));
+    v2f tn = q1.zw - no;
+    v2f r = {rcp(nd.x), rcp(nd.y)};
+    PairHit h;
+    h.t = tn * r;
+    v2f px = pfma(dx, h.t, ox), py = pfma(dy, h.t, oy), pz = pfma(dz, h.t, oz);
+    v2f uu = pfma(q3.xy, pz, pfma(q2.zw, py, q2.xy * px)) + q3.zw;
+    v2f vv = pfma(q5.xy, pz, pfma(q4.zw, py, q4.xy * px)) + q5.zw;
+    v2f mu = splat(1.0f) - uu, mv = splat(1.0f) - vv;
+    h.c.x = fminf(fminf(fminf(uu.x, vv.x), mu.x), mv.x);
+    h.c.y = fminf(fminf(fminf(uu.y, vv.y), mu.y), mv.y);
+    return h;
+}
+// pair k of the walk, whichever kind it is (k is wave-uniform: a scalar branch)
+ZD PairHit pair_test_k(const DScene &S, int k, f3 o, f3 d) {
+    return (k < S.nppairs) ? pair_test_par(as_constant(S.ppairs) + 6 * k, o, d) : pair_test(as_constant(S.pairs) + 10 * k, o, d);
+}
+
 // primitive of the pair walk -> slot and barycentrics of the triangle that was hit
 ZD void brute_resolve(const DScene &S, Hit &h, int prim, f3 o, f3 d) {
     if (prim < 0) { h.slot = -1; return; }
@@ -138,15 +163,19 @@ struct BruteAccel {
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
         int prim = -1;
-        const_v4f_ptr q = as_constant(S.pairs);
-#pragma unroll 1
-        for (int s = 0; s < S.nquads; s += 2, q += 10) {
-            PairHit ph = pair_test(q, o, d);
+        auto take = [&](const PairHit &ph, int s) {
             bool ok = (ph.t.x > tmin) & (ph.t.x < h.t) & (ph.c.x >= 0.0f);
             h.t = ok ? ph.t.x : h.t; prim = ok ? s : prim;
             ok = (ph.t.y > tmin) & (ph.t.y < h.t) & (ph.c.y >= 0.0f);
             h.t = ok ? ph.t.y : h.t; prim = ok ? s + 1 : prim;
-        }
+        };
+        const_v4f_ptr q = as_constant(S.ppairs);
+        int s = 0;
+#pragma unroll 1
+        for (; s < 2 * S.nppairs; s += 2, q += 6) take(pair_test_par(q, o, d), s);
+        q = as_constant(S.pairs) + 5 * s;
+#pragma unroll 1
+        for (; s < S.nquads; s += 2, q += 10) take(pair_test(q, o, d), s);
         brute_resolve(S, h, prim, o, d);
         return h;
     }
@@ -156,14 +185,13 @@ struct BruteAccel {
         if (S.ntris > 128) return closest(S, nullptr, o, d, 0.0f, 1e30f);   // more pairs than mask bits
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = 1e30f;
         int prim = -1;
-        const_v4f_ptr base = as_constant(S.pairs);
         unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mask), hi = __builtin_amdgcn_readfirstlane((unsigned)(mask >> 32));
         unsigned long long m = ((unsigned long long)hi << 32) | lo;
 #pragma unroll 1
         while (m) {
             const int k = __builtin_ctzll(m);
             m &= m - 1ull;
-            PairHit ph = pair_test(base + 10 * k, o, d);
+            PairHit ph = pair_test_k(S, k, o, d);
             const int s = 2 * k;
             bool ok = (ph.t.x > 0.0f) & (ph.t.x < h.t) & (ph.c.x >= 0.0f);
             h.t = ok ? ph.t.x : h.t; prim = ok ? s : prim;
@@ -175,12 +203,16 @@ struct BruteAccel {
     }
     ZD static bool any(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         bool occ = false;
-        const_v4f_ptr q = as_constant(S.pairs);
-#pragma unroll 1
-        for (int s = 0; s < S.nquads; s += 2, q += 10) {
-            PairHit ph = pair_test(q, o, d);
+        auto take = [&](const PairHit &ph) {
             occ |= ((ph.t.x > tmin) & (ph.t.x < tmax) & (ph.c.x >= 0.0f)) | ((ph.t.y > tmin) & (ph.t.y < tmax) & (ph.c.y >= 0.0f));
-        }
+        };
+        const_v4f_ptr q = as_constant(S.ppairs);
+        int s = 0;
+#pragma unroll 1
+        for (; s < 2 * S.nppairs; s += 2, q += 6) take(pair_test_par(q, o, d));
+        q = as_constant(S.pairs) + 5 * s;
+#pragma unroll 1
+        for (; s < S.nquads; s += 2, q += 10) take(pair_test(q, o, d));
         return occ;
     }
 };

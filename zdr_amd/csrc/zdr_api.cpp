@@ -153,7 +153,7 @@ static void plane_record(const h3 *p, float4 *out, float4 *w_out = nullptr) {
 // that edge, and the quad is convex (the apex of each lies strictly inside the other's two outer edges).  For each input
 // triangle `rot` says which corner is the apex (= corner 0 of its slot's records: the diagonal is then the w = 0 edge of
 // both triangles and the outer edges are their u = 0 and v = 0 edges); `quads` lists the merged pairs (input indices).
-struct QuadPair { int a, b; };
+struct QuadPair { int a, b; bool par; };   // par: a parallelogram (the second apex = s1 + s2 - first apex)
 static void find_quads(const std::vector<h3> &pos, uint32_t ntris, std::vector<int> &rot, std::vector<QuadPair> &quads) {
     rot.assign(ntris, 0); quads.clear();
     struct EdgeKey { float k[6]; bool operator<(const EdgeKey &o) const { return memcmp(k, o.k, sizeof k) < 0; } };
@@ -164,7 +164,7 @@ static void find_quads(const std::vector<h3> &pos, uint32_t ntris, std::vector<i
     for (uint32_t t = 0; t < ntris; t++) for (int e = 0; e < 3; e++) edges[key(pos[3 * (size_t)t + (e + 1) % 3], pos[3 * (size_t)t + (e + 2) % 3])].push_back({(int)t, e});
     auto D = [](h3 v, double *o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; };
     // which pairs COULD merge (t with corner e as its apex, t2 with corner e2)
-    struct Cand { int t2, e, e2; };
+    struct Cand { int t2, e, e2; bool par; };
     std::vector<std::vector<Cand>> adj(ntris);
     for (uint32_t t = 0; t < ntris; t++) {
         for (int e = 0; e < 3; e++) {
@@ -185,7 +185,7 @@ static void find_quads(const std::vector<h3> &pos, uint32_t ntris, std::vector<i
                 const double v = ((n[1] * e1[2] - n[2] * e1[1]) * r[0] + (n[2] * e1[0] - n[0] * e1[2]) * r[1] + (n[0] * e1[1] - n[1] * e1[0]) * r[2]) / nn;
                 if (!(u > 1e-6 && v > 1e-6 && 1.0 - u - v < -1e-6)) continue;                                   // not convex, or folded back
                 // (the corners at the two apices are corners of a triangle, hence convex: nothing else to check)
-                adj[t].push_back({t2, e, e2});
+                adj[t].push_back({t2, e, e2, fabs(u - 1.0) <= 2e-6 && fabs(v - 1.0) <= 2e-6});
             }
         }
     }
@@ -206,13 +206,14 @@ static void find_quads(const std::vector<h3> &pos, uint32_t ntris, std::vector<i
         }
         if (!best) continue;
         used[t] = used[best->t2] = 1; rot[t] = best->e; rot[best->t2] = best->e2;
-        quads.push_back({std::min(t, best->t2), std::max(t, best->t2)});
+        quads.push_back({std::min(t, best->t2), std::max(t, best->t2), best->par});
     }
-    std::sort(quads.begin(), quads.end(), [](const QuadPair &x, const QuadPair &y) { return x.a < y.a; });
+    // parallelograms first (their pairs take the shorter test of accel.h), each group in input order
+    std::sort(quads.begin(), quads.end(), [](const QuadPair &x, const QuadPair &y) { return x.par != y.par ? x.par : x.a < y.a; });
 }
 
 // Slot order of the brute-force walk: the two triangles of quad q in slots 2q and 2q + 1, the single triangles after them.
-static uint32_t brute_slot_order(const std::vector<h3> &pos, uint32_t ntris, std::vector<int> &order, std::vector<int> &rot) {
+static uint32_t brute_slot_order(const std::vector<h3> &pos, uint32_t ntris, std::vector<int> &order, std::vector<int> &rot, uint32_t *npar = nullptr) {
     std::vector<QuadPair> quads;
     rot.assign(ntris, 0);
     if (!getenv("ZDR_NO_QUADS")) find_quads(pos, ntris, rot, quads);
@@ -221,6 +222,7 @@ static uint32_t brute_slot_order(const std::vector<h3> &pos, uint32_t ntris, std
     uint32_t slot = 0;
     for (const QuadPair &q : quads) { order[slot++] = q.a; order[slot++] = q.b; in_quad[q.a] = in_quad[q.b] = 1; }
     for (uint32_t t = 0; t < ntris; t++) if (!in_quad[t]) order[slot++] = (int)t;
+    if (npar) { *npar = 0; for (const QuadPair &q : quads) *npar += q.par ? 1u : 0u; }
     return (uint32_t)quads.size();
 }
 
@@ -388,7 +390,8 @@ struct zdr_scene {
     std::vector<int32_t> inst_tri_begin;
     std::vector<float> emission;
     float4 *d_isect = nullptr, *d_pairs = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
-    uint32_t nquads = 0, nquads2 = 0;      // brute force: primitives of the pair walk, and how many of them are merged quads (find_quads)
+    uint32_t nquads = 0, nquads2 = 0, npar = 0;   // brute force: primitives of the pair walk, how many of them are merged quads (find_quads), how many of those parallelograms
+    float4 *d_ppairs = nullptr;
     float *d_emission = nullptr;
     // flat light table (scene.h): one 80-byte entry per triangle of every emitting instance + {first entry, count} per light
     std::vector<float4> tri_geo;            // host copy, 4 float4 per INPUT triangle: p0, p1, p2, {ng, area} (lights may change)
@@ -519,7 +522,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     if (!use_bvh) {
         std::vector<h3> pos(3 * (size_t)ntris);
         for (uint32_t t = 0; t < ntris; t++) for (int k = 0; k < 3; k++) pos[3 * (size_t)t + k] = rec[t].p[k];
-        s->nquads2 = brute_slot_order(pos, ntris, order, rot); s->nquads = ntris - s->nquads2;
+        s->nquads2 = brute_slot_order(pos, ntris, order, rot, &s->npar); s->nquads = ntris - s->nquads2;
     }
 
     std::vector<float4> isect(3 * (size_t)ntris + 3, make_float4(0, 0, 0, 0)), shade(8 * (size_t)ntris);   // + one record: the BVH walk fetches four float4 behind a leaf's first triangle
@@ -574,6 +577,17 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
             for (int k = 0; k < 20; k++) dst[2 * k] = ((const float *)src)[k];
         }
         up(&s->d_pairs, pr.data(), pr.size() * sizeof(float));
+        // pairs of two PARALLELOGRAMS (they come first): the outer edges of the second triangle are 1 - u and 1 - v of the first,
+        // so the record is the plane and two edge functions — six float4
+        const size_t nppairs = s->npar / 2;
+        std::vector<float> ppr(24 * std::max<size_t>(nppairs, 1), 0.0f);
+        for (uint32_t q = 0; q < 2 * nppairs; q++) {
+            const float *src = (const float *)&isect[3 * (size_t)(2 * q)];
+            float *dst = &ppr[24 * (size_t)(q / 2) + (q & 1)];
+            for (int k = 0; k < 12; k++) dst[2 * k] = src[k];
+        }
+        up(&s->d_ppairs, ppr.data(), ppr.size() * sizeof(float));
+        s->ds.nppairs = getenv("ZDR_NO_PARALLELOGRAMS") ? 0 : (int32_t)nppairs;
     }
     up(&s->d_shade, shade.data(), shade.size() * sizeof(float4));
     up(&s->d_nodes, nodes.data(), nodes.size() * sizeof(float4));
@@ -585,7 +599,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_error, sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemset(s->d_error, 0, sizeof(unsigned int));
     if (e != hipSuccess) { std::string m = hipGetErrorString(e); zdr_scene_destroy(s); return fail(ZDR_E_HIP, "scene upload: " + m); }
-    s->ds.isect = s->d_isect; s->ds.pairs = s->d_pairs; s->ds.shade = s->d_shade; s->ds.nodes = s->d_nodes; s->ds.emission = s->d_emission;
+    s->ds.isect = s->d_isect; s->ds.pairs = s->d_pairs; s->ds.ppairs = s->d_ppairs; s->ds.shade = s->d_shade; s->ds.nodes = s->d_nodes; s->ds.emission = s->d_emission;
     s->ds.light_insts = s->d_light_insts; s->ds.inst_tri_begin = s->d_inst_tri_begin; s->ds.slot_of_tri = s->d_slot_of_tri;
     s->ds.error_word = s->d_error;
     if (const char *e = getenv("ZDR_DEBUG_BVH_BUDGET")) s->ds.debug_bvh_budget = atoi(e);
@@ -627,7 +641,7 @@ extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int a
 extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
-    (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts); (void)hipFree(s->d_light_tris); (void)hipFree(s->d_light_range); (void)hipFree(s->d_emission4);
+    (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_ppairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts); (void)hipFree(s->d_light_tris); (void)hipFree(s->d_light_range); (void)hipFree(s->d_emission4);
     (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters); (void)hipFree(s->d_error);
     delete s;
     return ZDR_OK;

@@ -179,8 +179,9 @@ int zdr_path_dump(zdr_scene *scene, const zdr_render_params *params, const float
  * order_out[slot] = input triangle; isect_out: ntris x 12 floats (plane-form records, slot order).
  * Brute force (ZDR_ACCEL_BRUTE, or AUTO with <= 64 triangles): there are no nodes; *nnodes receives the number Q of
  * planar convex quads the walk merged out of coplanar triangle pairs — slots 2q and 2q + 1 for q < Q, the other
- * triangles after them — and the records of a quad's two triangles start at the corner OPPOSITE the shared edge
- * (tests/test_brute_quads.py). */
+ * triangles after them — and the records of a quad's two triangles start at the corner OPPOSITE the shared edge;
+ * *stack_entries receives how many of the quads are parallelograms (they come first; the walk tests them in pairs with
+ * the first triangle's u, v and 1 - u, 1 - v) (tests/test_brute_quads.py). */
 int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int accel, float *nodes_out, uint32_t nodes_cap,
                           uint32_t *nnodes, uint32_t *stack_entries, int32_t *order_out, float *isect_out);
 

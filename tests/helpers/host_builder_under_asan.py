@@ -13,13 +13,12 @@ import test_bvh_emulation as E
 import test_brute_quads as Q
 L = _native.lib()
 A = geometry.assemble(cbox_models())
-for accel in (_native.ACCEL_BRUTE, _native.ACCEL_BVH):
-    for arrays in (A, multi_light_arrays(), terrain_arrays(n=24)):
-        nodes, order, isect = E.build(arrays, accel)
-        print(accel, arrays.tris.shape[0], len(nodes), int(order.sum()))
 big = procedural.tessellated_cbox(cbox_models(), n=24)
-nodes, order, isect = E.build(big, _native.ACCEL_BVH); print("tess", big.tris.shape[0], len(nodes))
-nodes, order, isect = E.build(big, _native.ACCEL_BRUTE); print("tess brute quads", big.tris.shape[0])
+for arrays in (A, multi_light_arrays(), terrain_arrays(n=24), big):
+    nodes, order, isect = E.build(arrays, _native.ACCEL_BVH)
+    print("bvh", arrays.tris.shape[0], len(nodes), int(order.sum()))
+    nq, order, isect = Q.build(E.world_triangles(arrays))
+    print("brute", arrays.tris.shape[0], nq, Q.NPAR, int(order.sum()))
 print("quads", Q.build(A.verts[A.tris][:, :, :3])[0])
 Q.test_only_planar_convex_pairs_merge()
 # degenerate input: zero-area and NaN triangles must not crash the builders

@@ -15,6 +15,8 @@ def build(tris):
     rc = _native.lib().zdr_debug_build_accel(tri.ctypes.data, n, _native.ACCEL_BRUTE, nodes.ctypes.data, 1, C.byref(nq), C.byref(se),
                                               order.ctypes.data, isect.ctypes.data)
     assert rc == 0, _native.lib().zdr_last_error()
+    global NPAR
+    NPAR = se.value                      # parallelograms among the quads (they come first)
     return nq.value, order, isect
 
 
@@ -27,7 +29,7 @@ def test_cornell_box_is_fifteen_quads_and_two_triangles(cbox_arrays):
     A = cbox_arrays
     tris = A.verts[A.tris][:, :, :3]
     nq, order, isect = build(tris)
-    assert nq == 15 and sorted(order.tolist()) == list(range(32))
+    assert nq == 15 and NPAR == 11 and sorted(order.tolist()) == list(range(32))
     P = tris.reshape(32, 3, 3).astype(np.float64)
     for q in range(nq):
         a, b = order[2 * q], order[2 * q + 1]
@@ -60,7 +62,8 @@ def test_cornell_box_is_fifteen_quads_and_two_triangles(cbox_arrays):
 
 def test_only_planar_convex_pairs_merge():
     flat = quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0))
-    assert build(flat)[0] == 1
+    assert build(flat)[0] == 1 and NPAR == 1
+    assert build(quad((0, 0, 0), (1, 0, 0), (1.2, 1, 0), (0, 1, 0)))[0] == 1 and NPAR == 0      # a trapezium merges, but not as a parallelogram
     bent = quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 1e-3))              # fourth corner out of the plane
     assert build(bent)[0] == 0
     dart = quad((0, 0, 0), (1, 0, 0), (0.2, 0.2, 0), (0, 1, 0))             # reflex corner at the shared edge
@@ -100,7 +103,9 @@ def emulate_quad_walk(nq, order, isect, rays):
             t = ((N[3] - (o @ N[:3]).astype(f)) / (d @ N[:3]).astype(f)).astype(f)
             p = (o + d * t[:, None]).astype(f)
             u, v = edge(U, p), edge(V, p)
-            if q < nq:
+            if q < 2 * (NPAR // 2):                      # pairs of parallelograms: the second triangle's outer edges are 1 - u, 1 - v
+                e3, e4 = (f(1.0) - u).astype(f), (f(1.0) - v).astype(f)
+            elif q < nq:
                 e3, e4 = edge(isect[a + 1, 4:8], p), edge(isect[a + 1, 8:12], p)
             else:
                 e3 = e4 = (f(1.0) - (u + v)).astype(f)

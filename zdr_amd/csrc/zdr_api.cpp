@@ -621,7 +621,8 @@ extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int a
     bool use_bvh = (accel == ZDR_ACCEL_BVH) || (accel == ZDR_ACCEL_AUTO && ntris > 64);
     int rc = build_accel(pos, ntris, use_bvh, order, nodes, nn, depth, se); if (rc) return rc;
     std::vector<int> rot(ntris, 0);
-    if (!use_bvh) nn = brute_slot_order(pos, ntris, order, rot);      // brute force: *nnodes = merged quads (slots 2q, 2q + 1), no nodes
+    uint32_t npar = 0;
+    if (!use_bvh) { nn = brute_slot_order(pos, ntris, order, rot, &npar); se = npar; }   // brute force: *nnodes = merged quads (slots 2q, 2q + 1), *stack_entries = how many of them are parallelograms (they come first); no nodes
     *nnodes = nn;
     if (stack_entries) *stack_entries = se;
     if (use_bvh) {

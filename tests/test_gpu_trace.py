@@ -137,3 +137,25 @@ def test_million_triangle_tessellated_cbox():
     small = make_scene("path").render(m, res=(128, 128), spp=64, seed=1)[..., :3]
     assert abs(big.mean().item() - small.mean().item()) / small.mean().item() < 0.03
     assert not torch.isnan(big).any()
+
+
+@pytest.mark.parametrize("accel", ["bvh"])
+def test_reference_pinned_sphere(accel):
+    """sphere.obj as the REFERENCE's loader reads it (tests/golden/obj_fixtures.npz: 559 vertices, 960 triangles,
+    /root/reference/load_obj.py:1-68) under a small light: BVH closest / any hit against the oracle's brute force."""
+    import os
+    from conftest import ASSETS, GOLDEN
+    from zdr_amd import geometry
+    fx = np.load(os.path.join(GOLDEN, "obj_fixtures.npz"))
+    A = geometry.assemble([(os.path.join(ASSETS, "sphere.obj"), None, 0.0), (os.path.join(ASSETS, "cbox-light.obj"), None, 20.0)])
+    assert np.array_equal(A.tris[:960].reshape(-1), fx["sphere_triangles"])
+    np.testing.assert_array_equal(A.verts[:559, :5], fx["sphere_vertices"][:, :5].astype(np.float32))
+    scene = make_scene("path", arrays=A, accel=accel)
+    assert scene.info()["accel"] == "bvh" and scene.info()["ntris"] == 962
+    S = oracle.OracleScene.from_arrays(A)
+    lo, hi = A.verts[:559, :3].min(0) - 0.5, A.verts[:559, :3].max(0) + 0.5
+    rays = random_rays(60000, lo, hi, seed=9)
+    check_closest(scene, S, rays, "sphere.obj/bvh")
+    rays[:, 3] = 1e-4; rays[:, 7] = np.random.default_rng(10).uniform(0.05, 2.0, rays.shape[0]).astype(np.float32)
+    occ = scene.trace_any(torch.from_numpy(rays).cuda()).cpu().numpy()
+    assert (occ != S.trace_any(rays)).mean() < 2e-4

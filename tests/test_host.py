@@ -87,3 +87,38 @@ def test_value_types():
     np.testing.assert_array_equal(float4x4(1.0).rows(), np.eye(4))
     c = Camera(fov=0.5, origin=float3(1, 2, 3), target=float3(0), up=float3(0, 1, 0))
     assert c.copy().origin == c.origin and c.copy() is not c
+
+
+# --- reference-pinned: fixtures produced by the reference's own load_obj.py (tests/golden/make_obj_fixtures.py) ---
+
+OBJ_FIXTURES = {"cboxuv": "cboxuv.obj", "cbox_light": "cbox-light.obj", "quad": "quad.obj",
+                "cbox_combined": "cbox-combined.obj", "sphere": "sphere.obj"}
+
+
+@pytest.mark.parametrize("key", sorted(OBJ_FIXTURES))
+def test_read_obj_reproduces_the_reference_loader(key):
+    """SURVEY row a20, pinned by the reference itself: /root/reference/load_obj.py:1-68 was run on this
+    very file and its vertex tuples, faces and triangle list stored in obj_fixtures.npz."""
+    from conftest import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, "obj_fixtures.npz"))
+    verts, faces = read_obj(os.path.join(ASSETS, OBJ_FIXTURES[key]))
+    got = np.array([list(p) + list(t) + list(n) for p, t, n in verts], np.float64).reshape(-1, 8)
+    want = fx[key + "_vertices"]
+    assert got.shape == want.shape
+    assert np.array_equal(got, want, equal_nan=True)                      # float64 parse, bit for bit; NaN normals in place
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    offs = fx[key + "_face_offsets"]
+    assert [len(f) for f in faces] == list(np.diff(offs))
+    assert np.array_equal(np.array([i for f in faces for i in f], np.int64), fx[key + "_faces"])
+    assert np.array_equal(np.array(concat_triangles(faces), np.int64), fx[key + "_triangles"])
+
+
+def test_assemble_on_the_reference_pinned_sphere():
+    """sphere.obj (960 triangles, 559 de-duplicated vertices by the reference's loader) through scene assembly:
+    index ranges, unit normals kept, and the float32 vertex rows are the fixture's float64 rows rounded once."""
+    from conftest import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, "obj_fixtures.npz"))
+    A = geometry.assemble([(os.path.join(ASSETS, "sphere.obj"), None, 0.0)])
+    assert A.verts.shape == (559, 8) and A.tris.shape == (960, 3)
+    assert np.array_equal(A.tris.reshape(-1), fx["sphere_triangles"].astype(A.tris.dtype))
+    np.testing.assert_array_equal(A.verts[:, :5], fx["sphere_vertices"][:, :5].astype(np.float32))

@@ -5,17 +5,21 @@ One step = scene.render(material, res, spp, seed=random) followed by I.sum().bac
 /root/reference/benchmark.py:36-39.  `value` = camera samples processed per second over both passes
 (2 * W * H * spp per step), inputs resident in HBM.
 
-  --gpus 1 (default)  BASELINE configs[2]: cbox, path integrator, 512x512, spp 256, textures cboxd/cboxr
+  --gpus 1 (default)  BASELINE configs[2]: cbox, path integrator, 512x512, spp 256, textures cboxd/cboxr — the headline
+                      line — and, in the same JSON line under "configs", the other configurations that fit one GPU, each
+                      timed the same way on its own scene: c2 (direct 512^2 spp 64), c4_one_gpu (path 1024^2 spp 1024, the
+                      8-GPU workload on one GPU) and c5 (1,004,672-triangle tessellated cbox, path 1024^2 spp 256)
   --gpus N > 1        BASELINE configs[3]: cbox path 1024x1024 spp 1024, ONE render pixel-tiled over the N ranks
                       (8x8 tiles dealt round-robin, one launch per rank and pass) and one RCCL all_reduce of the image
                       and of the gradient per step: fixed total work, "scaling": "strong"
-  --config c5         BASELINE configs[4]: 1,004,672-triangle tessellated cbox (BVH), path + PRB 1024x1024 spp 256,
-                      on 1 or N GPUs (tiled like c4)
+  --config c5         BASELINE configs[4] as the headline, on 1 or N GPUs (tiled like c4)
 
-Launch: `python bench.py --gpus N ...` starts its N ranks itself (torch.distributed.run as a child process, before
-this process has touched a GPU); under torchrun (WORLD_SIZE set) it is one of the ranks.
+Launch: `python bench.py --gpus N ...` starts its N ranks itself (torch.distributed.run as a child process; the parent
+never loads torch or touches a GPU); under torchrun (WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
+import gc
+import glob
 import json
 import os
 import random
@@ -26,16 +30,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-CONFIGS = {   # name: (integrator, res, spp, scene, BASELINE.json configs index)
-    "c2": ("direct", 512, 64, "cbox", 1),
-    "c3": ("path", 512, 256, "cbox", 2),
-    "c4": ("path", 1024, 1024, "cbox", 3),
-    "c5": ("path", 1024, 256, "tess1m", 4),
-}
+NAMES = {"c2": "cbox direct", "c3": "cbox path", "c4": "cbox path", "c5": "1,004,672-triangle tessellated cbox, path"}
 
 
 def parse_args():
@@ -43,21 +40,47 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="auto", choices=["auto", *CONFIGS])
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c3", "c4", "c5"])
     ap.add_argument("--res", type=int, default=0, help="override the configuration's resolution")
     ap.add_argument("--spp", type=int, default=0, help="override the configuration's samples per pixel")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "rows", "samples", "seeds"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="headline line only (skip the c2 / c4_one_gpu / c5 legs of the default run)")
     ap.add_argument("--cpu-spp", type=int, default=16)
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """GPUs this process tree may use, WITHOUT loading a GPU runtime: the KFD topology lists every agent and a GPU is a
+    node with SIMDs; HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES narrow it.  None when the topology cannot be read (the ranks
+    then fail on their own if a device is missing)."""
+    n = 0
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                                                # no amdgpu compute driver at all
+    props = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not props:
+        return None
+    for path in props:
+        try:
+            for line in open(path):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except OSError:
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args) -> int:
-    """The parent of an N-rank run: never touches a GPU, starts torchrun as a CHILD process and passes its output on."""
-    import torch
+    """The parent of an N-rank run: loads neither torch nor HIP, starts torchrun as a CHILD process and hands its exit
+    code on.  A process that has touched the GPU is never re-executed or restarted."""
     share = os.environ.get("ZDR_SHARE_DEVICE") == "1"          # rehearsal: every rank on cuda:0 over gloo
-    have = torch.cuda.device_count()                             # counting devices does not initialise HIP
-    if have < (1 if share else args.gpus):
+    have = visible_gpu_count()
+    if have is not None and have < (1 if share else args.gpus):
         print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this machine has {have}", file=sys.stderr)
         return 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -76,47 +99,55 @@ def algorithmic_bytes(stats, spp, backward):
     return a, (H, V, E)
 
 
-def pmc_traffic(kernel, workload_key):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (separate rocprofv3 --pmc runs of the same
-    workload, tools/pmc_passes.sh -> profiles/pmc_traffic.json); None when the workload was not profiled."""
+def pmc_record(kernel, workload_key):
+    """Counter figures per launch of `kernel` from the committed PMC passes (separate rocprofv3 --pmc runs of the same
+    workload, tools/pmc_passes.sh -> profiles/pmc_traffic.json).  The file carries the hash of the kernel sources it was
+    measured on: returns (record or None, stale) — stale when the sources in this tree hash differently."""
+    from zdr_amd import build as hip_build
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return d[kernel]["traffic_bytes"] if d.get("workload_key", "c3") == workload_key else None
     except Exception:
-        return None
+        return None, False
+    if d.get("workload_key", "c3") != workload_key or kernel not in d:
+        return None, False
+    return d[kernel], d.get("csrc_sha256") != hip_build.source_hash()
 
 
 def cpu_baseline(scene, mat_np, W, spp_sample):
     """The oracle (a scalar C port, OpenMP over pixels) on the host cores, bounded sample of the same workload."""
     import numpy as np
     import oracle
-    from gpu_util import oracle_params
     S = oracle.OracleScene.from_arrays(scene._arrays)
     threads = len(os.sched_getaffinity(0))                  # the CPUs this process may run on = the OpenMP threads asked for
-    p = oracle_params(scene, W, W, spp_sample, 0, mat_np.shape[:2], nthreads=threads)
+    cam = scene.camera
+    def params(seed):
+        return oracle.make_params(scene.integrator, W, W, spp_sample, seed, (cam.fov, tuple(cam.origin), tuple(cam.target), tuple(cam.up)), mat_np.shape[:2],
+                                  use_tent=scene.use_tent_filter, max_depth=scene.max_depth, rr_depth=scene.rr_depth, nthreads=threads)
     t0 = time.time()
-    S.render_forward(p, mat_np)
+    S.render_forward(params(0), mat_np)
     t1 = time.time()
-    S.render_backward(oracle_params(scene, W, W, spp_sample, 1, mat_np.shape[:2], nthreads=threads), np.ones((W, W, 4), np.float32), mat_np)
+    S.render_backward(params(1), np.ones((W, W, 4), np.float32), mat_np)
     t2 = time.time()
     n = W * W * spp_sample
-    return {"value": round(2 * n / (t2 - t0) / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{scene.integrator} {W}x{W} spp={spp_sample} fwd+bwd ({2 * n / 1e6:.1f} Msamples) of the same scene, oracle/zdr_oracle.c with OpenMP",
-            "fwd_msamples_s": round(n / (t1 - t0) / 1e6, 3), "bwd_msamples_s": round(n / (t2 - t1) / 1e6, 3)}
+    return {"value": float(f"{2 * n / (t2 - t0) / 1e6:.4g}"), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{scene.integrator} {W}x{W} spp={spp_sample} fwd+bwd ({2 * n} camera samples) of the same scene, oracle/zdr_oracle.c with OpenMP"
+                      + (" (brute force over every triangle: the oracle has no BVH)" if scene._arrays.tris.shape[0] > 10000 else ""),
+            "samples": 2 * n, "seconds": round(t2 - t0, 3),
+            "fwd_msamples_s": float(f"{n / (t1 - t0) / 1e6:.4g}"), "bwd_msamples_s": float(f"{n / (t2 - t1) / 1e6:.4g}")}
 
 
 def fd_summary():
     """Gradient accuracy against finite differences, measured by tools/fd_validate.py / tools/fd_directional.py."""
     out = {}
     for key, name in (("fd_validate_procedure_diffuse_texel", "fd_validate_diffuse_texel"), ("fd_validate_procedure_roughness_texel", "fd_validate_roughness_texel")):
-        for rnd in ("r2", "r1"):
+        for rnd in ("r3", "r2", "r1"):
             try:
                 t = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")))["tail"]
                 out[key] = {"rel_err": t["rel_err"], "one_sigma": t["one_sigma"], "spp": t["spp"], "seeds": t["seeds"], "source": f"profiles/{rnd}_{name}.json"}
                 break
             except Exception:
                 continue
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_fd_directional.json")))["result"]
             out["whole_image_directional"] = {k: {"rel_err": v["rel_err"], "one_sigma": v["one_sigma"]} for k, v in d.items()}
@@ -127,6 +158,136 @@ def fd_summary():
     return out or None
 
 
+class Leg:
+    """One timed workload: `steps` steps of render + backward on one scene, HIP events around the native calls."""
+
+    def __init__(self, scene, material, W, spp, renderer=None, world=1):
+        import torch
+        self.torch, self.scene, self.material, self.W, self.spp, self.renderer, self.world = torch, scene, material, W, spp, renderer, world
+        self.ev = {"fwd": [], "bwd": []}
+        self.timing = False
+        self.seeds = random.Random(0)
+        scene.render_forward = self._timed("fwd", scene.render_forward)
+        scene.render_backward = self._timed("bwd", scene.render_backward)
+
+    def _timed(self, name, fn):
+        # HIP events directly around the native calls, on the stream the kernels are enqueued on (torch's current one)
+        def wrapper(*a, **k):
+            if not self.timing:
+                return fn(*a, **k)
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record(); r = fn(*a, **k); e1.record()
+            self.ev[name].append((e0, e1))
+            return r
+        return wrapper
+
+    def step(self):
+        seed = self.seeds.randint(0, 2147483646)                # benchmark.py:38, capped so seed + 1 fits
+        self.material.grad = None
+        res = (self.W, self.W)
+        img = self.renderer.render(self.material, res=res, spp=self.spp, seed=seed) if self.world > 1 else self.scene.render(self.material, res=res, spp=self.spp, seed=seed)
+        img.sum().backward()
+
+    def run(self, steps, warmup):
+        import torch.distributed as dist
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        if self.world > 1: dist.barrier()
+        torch.cuda.synchronize()
+        self.timing = True
+        if self.renderer is not None: self.renderer.reduce_events = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        if self.world > 1: dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        self.timing = False
+        self.scene.check()                                      # a tripped device watchdog would make the numbers meaningless
+        self.steps = steps
+        self.dt = dt
+        self.launches = {k: len(v) // max(steps, 1) for k, v in self.ev.items()}
+        self.fwd_ms = sum(a.elapsed_time(b) for a, b in self.ev["fwd"]) / max(steps, 1)      # this rank's launches of one step
+        self.bwd_ms = sum(a.elapsed_time(b) for a, b in self.ev["bwd"]) / max(steps, 1)
+        return dt
+
+    def stats(self, shard):
+        """Path statistics of this rank's share of one pass (the counting kernel variant, zdr_render_stats)."""
+        st = {}
+        for rect in shard.rects:
+            for k, v in self.scene.render_stats(self.material.detach(), (self.W, self.W), self.spp, seed=0, rect=rect, samples=shard.samples, tile_shard=shard.tile_shard).items():
+                st[k] = st.get(k, 0) + v
+        return st
+
+    def roofline(self, stats, integrator, accel):
+        a_fwd, (Hb, Vb, Eb) = algorithmic_bytes(stats, self.spp, False)
+        a_bwd, _ = algorithmic_bytes(stats, self.spp, True)
+        n_rank = stats["samples"]                               # camera samples this rank processes per pass
+        nb = max(self.launches["bwd"], 1)
+        bwd_kernel_ms = self.bwd_ms / nb                        # dominant kernel = the backward kernel, average launch
+        achieved = a_bwd * (n_rank / nb) / (bwd_kernel_ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "kernel": f"k_path_bwd<cmj, {accel}>" if integrator == "path" else f"k_simple<{integrator}, backward>",
+             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+             "launch_ms": round(bwd_kernel_ms, 3), "algorithmic_bytes_per_launch": round(a_bwd * n_rank / nb),
+             "bytes_per_sample": {"fwd": round(a_fwd, 1), "bwd": round(a_bwd, 1)},
+             "fwd_achieved": round(a_fwd * n_rank / (self.fwd_ms * 1e-3) / 1e9, 2), "fwd_frac": round(a_fwd * n_rank / (self.fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        ps = {"closest_hits_per_sample": round(Hb, 4), "shaded_vertices_per_sample": round(Vb, 4), "emitter_hits_bsdf_per_sample": round(Eb, 5),
+              "closest_rays_per_sample": round(stats["closest_rays"] / stats["samples"], 4)}
+        return r, ps, n_rank
+
+
+def pmc_fields(roof, kernel, cfg, stats, active):
+    """What actually bounds the kernel, from the committed counter passes: `bound` stays the nominal HBM roofline the
+    contract asks for; VALU issue, lane utilisation and atomic requests per shaded vertex say what the kernel is limited by."""
+    rec, stale = pmc_record(kernel, cfg) if active else (None, False)
+    roof["traffic"] = None if (rec is None or stale) else rec.get("traffic_bytes")
+    roof["traffic_unit"] = "bytes per launch (rocprofv3 --pmc, profiles/pmc_traffic.json)"
+    if rec is not None:
+        roof["traffic_stale"] = bool(stale)
+        if not stale:
+            cyc = rec.get("gpu_cycles_per_xcd")
+            if rec.get("SQ_ACTIVE_INST_VALU") and cyc:
+                roof["valu_issue_frac"] = round(rec["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), 4)    # busy cycles summed over the SIMDs: x4 per wave64 instruction, 1024 SIMDs
+            if rec.get("valu_lane_utilisation"):
+                roof["lane_utilisation"] = round(rec["valu_lane_utilisation"], 4)
+            if rec.get("atomic_requests") and stats.get("shaded_vertices"):
+                roof["atomic_requests_per_vertex"] = round(rec["atomic_requests"] / stats["shaded_vertices"], 4)
+            roof["measured_bound"] = rec.get("measured_bound", "valu_issue")
+    return roof
+
+
+def extra_config(name, cfg_key, dev, mat_np, steps, warmup):
+    """One more BASELINE configuration on this GPU, timed like the headline: its own scene, its own path statistics."""
+    import torch
+    from zdr_amd import distributed as zd
+    from zdr_amd import scenes
+    t_build = time.perf_counter()
+    scene, W, spp = scenes.config_scene(cfg_key)
+    t_build = time.perf_counter() - t_build
+    material = torch.from_numpy(mat_np).to(dev).requires_grad_()
+    leg = Leg(scene, material, W, spp)
+    dt = leg.run(steps, warmup)
+    stats = leg.stats(zd.plan("tiles", 0, 1, (W, W), spp, 0))
+    integrator = scenes.CONFIGS[cfg_key][0]
+    accel = scene.info()["accel"]
+    roof, ps, n = leg.roofline(stats, integrator, accel)
+    out = {"workload": f"{NAMES[cfg_key]} integrator {W}x{W} spp={spp} (BASELINE configs[{scenes.CONFIGS[cfg_key][4]}])" + (" on ONE GPU" if cfg_key == "c4" else ""),
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "msamples_s": round(2 * n * steps / dt / 1e6, 2),
+           "fwd_ms": round(leg.fwd_ms, 3), "bwd_ms": round(leg.bwd_ms, 3),
+           "fwd_msamples_s": round(n / (leg.fwd_ms * 1e-3) / 1e6, 2), "bwd_msamples_s": round(n / (leg.bwd_ms * 1e-3) / 1e6, 2),
+           "accel": accel, "scene_build_s": round(t_build, 2), "path_stats": ps,
+           "bytes_per_sample": roof["bytes_per_sample"],
+           "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms", "fwd_achieved", "fwd_frac")}}
+    if accel == "bvh":
+        out["triangles"] = scene.info()["ntris"]
+    scene.render_forward = scene.render_backward = None     # break the cycle scene -> timing wrapper -> leg -> scene
+    del leg, scene, material
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -135,116 +296,84 @@ def main():
     if world_env is not None and int(world_env) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with matching values")
 
-    import numpy as np
     import torch
     import torch.distributed as dist
-    from conftest import cbox_material_np, cbox_models
-    from gpu_util import make_scene
     from zdr_amd import distributed as zd
+    from zdr_amd import scenes
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an AMD GPU: the renderer has no CPU back end")
+    if world_env is not None and os.environ.get("ZDR_SHARE_DEVICE") != "1" and torch.cuda.device_count() < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this rank sees {torch.cuda.device_count()}")
     rank, world, local = zd.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = args.config if args.config != "auto" else ("c3" if world == 1 else "c4")
-    integrator, W, spp, scene_kind, cfg_index = CONFIGS[cfg]
+    integrator, W, spp, scene_kind, cfg_index = scenes.CONFIGS[cfg]
     W, spp = args.res or W, args.spp or spp
-    if scene_kind == "tess1m":
-        from zdr_amd import procedural
-        scene = make_scene(integrator, arrays=procedural.tessellated_cbox(cbox_models(), n=183))
-    else:
-        scene = make_scene(integrator)
-    mat_np = cbox_material_np()
+    scene = scenes.make_scene(integrator, arrays=scenes.tess1m_arrays()) if scene_kind == "tess1m" else scenes.make_scene(integrator)
+    mat_np = scenes.cbox_material_np()
     material = torch.from_numpy(mat_np).to(dev).requires_grad_()
     renderer = zd.attach(scene, mode=args.shard)
-    seeds = random.Random(0)
-
-    # HIP events directly around the native calls, on the stream the kernels are enqueued on (torch's current one)
-    ev = {"fwd": [], "bwd": []}
-    timing = [False]
-
-    def timed(name, fn):
-        def wrapper(*a, **k):
-            if not timing[0]:
-                return fn(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); r = fn(*a, **k); e1.record()
-            ev[name].append((e0, e1))
-            return r
-        return wrapper
-    scene.render_forward = timed("fwd", scene.render_forward)
-    scene.render_backward = timed("bwd", scene.render_backward)
-
-    def step():
-        seed = seeds.randint(0, 2147483646)                 # benchmark.py:38, capped so seed + 1 fits
-        material.grad = None
-        img = renderer.render(material, res=(W, W), spp=spp, seed=seed) if world > 1 else scene.render(material, res=(W, W), spp=spp, seed=seed)
-        img.sum().backward()
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1: dist.barrier()
-    torch.cuda.synchronize()
-    timing[0] = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1: dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timing[0] = False
+    leg = Leg(scene, material, W, spp, renderer, world)
+    dt_rank = leg.run(args.steps, args.warmup)
+    dt = dt_rank
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt_rank], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    scene.check()                                           # a tripped device watchdog would make the numbers meaningless
+        # outside the timed region: what every rank measured, so that a shortfall can be attributed to imbalance
+        # (kernel time differs between ranks) or to communication (all-reduce time)
+        red = renderer.reduce_ms()
+        mine = torch.tensor([dt_rank / args.steps * 1e3, leg.fwd_ms, leg.bwd_ms, red["image"] / args.steps, red["gradient"] / args.steps], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu().numpy()
 
     n_per_pass = W * W * spp                                # camera samples of one whole pass (all ranks together)
     weak = world > 1 and args.shard == "seeds"
-    launches = {k: len(v) // max(args.steps, 1) for k, v in ev.items()}
-    fwd_ms = sum(a.elapsed_time(b) for a, b in ev["fwd"]) / max(args.steps, 1)      # this rank's launches of one step
-    bwd_ms = sum(a.elapsed_time(b) for a, b in ev["bwd"]) / max(args.steps, 1)
 
     if rank == 0:
-        shard = zd.plan(args.shard, 0, world, (W, W), spp, 0)
-        stats = {}
-        for rect in shard.rects:                            # path statistics of rank 0's share of one pass
-            for k, v in scene.render_stats(material.detach(), (W, W), spp, seed=0, rect=rect, samples=shard.samples, tile_shard=shard.tile_shard).items():
-                stats[k] = stats.get(k, 0) + v
-        a_fwd, (Hb, Vb, Eb) = algorithmic_bytes(stats, spp, False)
-        a_bwd, _ = algorithmic_bytes(stats, spp, True)
-        n_rank = stats["samples"]                           # camera samples rank 0 processes per pass
-        bwd_kernel_ms = bwd_ms / max(launches["bwd"], 1)    # dominant kernel = the PRB backward kernel, average launch
-        achieved = a_bwd * (n_rank / max(launches["bwd"], 1)) / (bwd_kernel_ms * 1e-3) / 1e9
+        stats = leg.stats(zd.plan(args.shard, 0, world, (W, W), spp, 0))
         accel = scene.info()["accel"]
-        names = {"c2": "cbox direct", "c3": "cbox path", "c4": "cbox path", "c5": "1,004,672-triangle tessellated cbox, path"}
+        roof, ps, n_rank = leg.roofline(stats, integrator, accel)
+        roof = pmc_fields(roof, "k_path_bwd", cfg, stats, (world, integrator) == (1, "path") and not (args.res or args.spp))
         out = {
-            "metric": "Msamples/s fwd+PRB-bwd" + (", cbox 512x512 spp=256" if (cfg, W, spp) == ("c3", 512, 256) else f", {names[cfg]} {W}x{W} spp={spp}"),
+            "metric": "Msamples/s fwd+PRB-bwd" + (", cbox 512x512 spp=256" if (cfg, W, spp) == ("c3", 512, 256) else f", {NAMES[cfg]} {W}x{W} spp={spp}"),
             "value": round(2 * n_per_pass * args.steps * (world if weak else 1) / dt / 1e6, 2),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (random seeds; cbox geometry + cboxd/cboxr textures" + ("; instance 0 tessellated and displaced, seed 0)" if cfg == "c5" else ")"),
-            "config": {"workload": f"{names[cfg]} integrator {W}x{W} spp={spp}, forward + PRB backward w.r.t. the 1024x1024x4 material (BASELINE configs[{cfg_index}])",
+            "config": {"workload": f"{NAMES[cfg]} integrator {W}x{W} spp={spp}, forward + PRB backward w.r.t. the 1024x1024x4 material (BASELINE configs[{cfg_index}])",
                        "sampler": "cmj", "shard": args.shard if world > 1 else "none", "accel": accel,
                        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else "none",
-                       "launches_per_step_per_rank": launches},
-            "fwd_msamples_s": round(n_rank / (fwd_ms * 1e-3) / 1e6, 2), "bwd_msamples_s": round(n_rank / (bwd_ms * 1e-3) / 1e6, 2),
-            "fwd_ms": round(fwd_ms, 3), "bwd_ms": round(bwd_ms, 3),
+                       "launches_per_step_per_rank": leg.launches},
+            "fwd_msamples_s": round(n_rank / (leg.fwd_ms * 1e-3) / 1e6, 2), "bwd_msamples_s": round(n_rank / (leg.bwd_ms * 1e-3) / 1e6, 2),
+            "fwd_ms": round(leg.fwd_ms, 3), "bwd_ms": round(leg.bwd_ms, 3),
             "per_rank_note": "fwd/bwd figures are rank 0's kernels on its share of the pass (HIP events around the native calls)" if world > 1 else "HIP events around the native calls",
-            "path_stats": {"closest_hits_per_sample": round(Hb, 4), "shaded_vertices_per_sample": round(Vb, 4), "emitter_hits_bsdf_per_sample": round(Eb, 5),
-                           "closest_rays_per_sample": round(stats["closest_rays"] / stats["samples"], 4)},
-            "roofline": {"bound": "hbm", "kernel": f"k_path_bwd<cmj, {accel}>" if integrator == "path" else f"k_simple<{integrator}, backward>",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": pmc_traffic("k_path_bwd", cfg) if (world, integrator) == (1, "path") and not (args.res or args.spp) else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 --pmc, profiles/pmc_traffic.json)",
-                         "launch_ms": round(bwd_kernel_ms, 3), "algorithmic_bytes_per_launch": round(a_bwd * n_rank / max(launches["bwd"], 1)),
-                         "bytes_per_sample": {"fwd": round(a_fwd, 1), "bwd": round(a_bwd, 1)},
-                         "fwd_achieved": round(a_fwd * n_rank / (fwd_ms * 1e-3) / 1e9, 2)},
+            "path_stats": ps, "roofline": roof,
         }
+        if per_rank is not None:
+            col = lambda i: {"min": round(float(per_rank[:, i].min()), 3), "max": round(float(per_rank[:, i].max()), 3)}
+            out["per_rank_ms"] = {"step": col(0), "fwd_kernels": col(1), "bwd_kernels": col(2),
+                                  "note": "per step; step = wall clock of the timed loop / steps on each rank, kernels = HIP events around the native calls"}
+            out["allreduce_ms"] = {"image": col(3), "gradient": col(4), "bytes": {"image": W * W * 16, "gradient": int(material.numel()) * 4},
+                                   "note": "per step, HIP events on the compute stream around torch.distributed.all_reduce (includes waiting for the slowest rank)"}
         fd = fd_summary()
         if fd: out["grad_rel_err_vs_fd"] = fd
+        if world == 1 and cfg == "c3" and not (args.res or args.spp) and not args.no_extra_configs:
+            # the other single-GPU BASELINE configurations, each on its own scene with its own statistics (c5: BVH built once, 2 steps)
+            scene.render_forward = scene.render_backward = None
+            del leg, renderer, scene
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["configs"] = {}
+            for name, key, steps, warm in (("c2", "c2", 10, 2), ("c4_one_gpu", "c4", 2, 1), ("c5", "c5", 2, 1)):
+                out["configs"][name] = extra_config(name, key, dev, mat_np, steps, warm)
+            scene = scenes.make_scene(integrator)
         if world == 1 and not args.no_cpu_baseline:
+            # only now is the CPU oracle loaded — after every timed region
             out["cpu_baseline"] = cpu_baseline(scene, mat_np, min(W, 512) if cfg != "c5" else 64, args.cpu_spp if cfg != "c5" else 4)
         print(json.dumps(out), flush=True)
     if world > 1:

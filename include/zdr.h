@@ -22,7 +22,10 @@
 extern "C" {
 #endif
 
-#define ZDR_VERSION_STRING "zdr-mi355x 0.1 (gfx950)"
+#define ZDR_VERSION_STRING "zdr-mi355x 0.3 (gfx950)"
+/* Bumped whenever a struct of this header changes size or meaning (2: tile shard + prb_mode fields; 3: struct_size).
+ * A binding asserts zdr_abi_version() == ZDR_ABI_VERSION of the header it was written against. */
+#define ZDR_ABI_VERSION 3
 
 enum { ZDR_OK = 0, ZDR_E_INVALID = -1, ZDR_E_HIP = -2, ZDR_E_UNSUPPORTED = -3, ZDR_E_NOMEM = -4 };
 
@@ -46,6 +49,7 @@ typedef struct {
 /* Arguments of one kernel dispatch (integrator.py:10-11, render.py:168-171,193-196) plus the
  * shard this call covers: a pixel rectangle and a sample-index range. */
 typedef struct {
+    uint32_t struct_size;              /* = sizeof(zdr_render_params) of the caller's header; a mismatch is ZDR_E_INVALID */
     int32_t integrator;                /* ZDR_COLLOCATED | ZDR_DIRECT | ZDR_PATH */
     int32_t sampler;                   /* ZDR_SAMPLER_* */
     int32_t width, height;             /* res = (W, H); image tensor is (H, W, 4) */
@@ -81,6 +85,7 @@ typedef struct {
 } zdr_scene_info_t;
 
 const char *zdr_version(void);
+int zdr_abi_version(void);             /* ZDR_ABI_VERSION the library was built with */
 const char *zdr_last_error(void);
 
 /* Replaces Scene.load_geometry (render.py:73-128): luisa.Buffer uploads, accel.add(vb, tb,

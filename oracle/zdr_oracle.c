@@ -1257,6 +1257,7 @@ int zdro_path_dump(const zdro_scene *s, const zdro_params *P, const float *mater
         const int x = queries[3 * i], y = queries[3 * i + 1]; const uint32_t it = (uint32_t)queries[3 * i + 2];
         float *o = out + (size_t)i * stride;
         memset(o, 0, sizeof(float) * stride);
+        if (x < 0 || y < 0 || x >= P->width || y >= P->height || it >= P->spp) continue;   /* as the GPU twin: such a query reads as all zeros */
         v3 le_grad = V3(1.0f / (float)P->spp, 1.0f / (float)P->spp, 1.0f / (float)P->spp);
         if (d_image) {
             const float *g = d_image + 4 * ((size_t)x + (size_t)y * P->width);

@@ -5,12 +5,7 @@ import torch
 import oracle
 from conftest import CBOX_CAMERA, cbox_models
 from zdr_amd import Camera, Scene, float3, geometry
-
-
-def make_scene(integrator, accel="auto", models=None, arrays=None):
-    s = Scene(arrays if arrays is not None else (models or cbox_models()), integrator=integrator, accel=accel)
-    s.camera = Camera(fov=CBOX_CAMERA[0], origin=float3(*CBOX_CAMERA[1]), target=float3(*CBOX_CAMERA[2]), up=float3(*CBOX_CAMERA[3]))
-    return s
+from zdr_amd.scenes import make_scene  # noqa: F401  (re-exported)
 
 
 def oracle_params(scene, W, H, spp, seed, tex_hw, **kw):

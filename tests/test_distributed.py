@@ -21,14 +21,10 @@ def _oracle_renderer(mode):
     S = oracle.OracleScene.from_arrays(geometry.assemble(cbox_models()))
 
     def tiles_of(rect, tile_shard):
-        # the oracle knows rectangles only: an interleaved tile shard (include/zdr.h) is the list of its 8x8 tiles
-        if tile_shard is None:
-            return [rect]
-        x0, y0, x1, y1 = rect
-        index, count = tile_shard
-        tx = (x1 - x0 + 7) // 8; ty = (y1 - y0 + 7) // 8
-        return [(x0 + 8 * (t % tx), y0 + 8 * (t // tx), min(x0 + 8 * (t % tx) + 8, x1), min(y0 + 8 * (t // tx) + 8, y1))
-                for t in range(index, tx * ty, count)]
+        # the oracle knows rectangles only: an interleaved tile shard is the list of its 8x8 tiles, numbered along the
+        # diagonals exactly as the kernels do (zd.shard_tiles mirrors decode_item; tests/test_gpu_render.py checks the
+        # kernels' ownership against the same function)
+        return [rect] if tile_shard is None else zd.shard_tiles(rect, *tile_shard)
 
     def fwd(material, res, spp, seed, rect, samples, out, tile_shard=None):
         for r in tiles_of(rect, tile_shard):
@@ -94,6 +90,46 @@ def test_two_ranks_reproduce_the_single_process_render(mode):
     else:
         np.testing.assert_allclose(img, ref_img, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(grad, ref_grad, rtol=1e-4, atol=1e-7)
+
+
+def test_eight_ranks_tile_union_is_bit_identical():
+    """BASELINE configs[3]'s layout at its rank count: 8 gloo ranks, `tiles` mode, 24 x 24 pixels = 9 tiles (rank 8 of 8
+    owns one tile, most own one, one owns two), oracle as the local renderer.  The union is the unsharded image bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, "tiles", q)) for r in range(8)]
+    for p in procs: p.start()
+    img, grad = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120); assert p.exitcode == 0
+    import oracle
+    from zdr_amd import geometry
+    S = oracle.OracleScene.from_arrays(geometry.assemble(cbox_models()))
+    mat = fd_material_np(32, 2)
+    ref = S.render_forward(oracle.make_params("path", W, W, SPP, SEED, CBOX_CAMERA, mat.shape[:2]), mat)
+    gref = S.render_backward(oracle.make_params("path", W, W, SPP, SEED + 1, CBOX_CAMERA, mat.shape[:2]), np.full((W, W, 4), 0.5, np.float32), mat)
+    assert np.array_equal(img, ref)
+    np.testing.assert_allclose(grad, gref, rtol=1e-4, atol=1e-7)
+
+
+def test_shard_tiles_partition_along_diagonals():
+    """zd.shard_tiles = the ownership mapping of include/zdr.h: the shards of one count partition the rectangle, and tile
+    (tx, ty) belongs to shard (ty * tiles_x + (tx - ty) mod tiles_x) mod count — diagonals, not columns."""
+    from zdr_amd import distributed as zd
+    rect = (13, 7, 90, 60)                                      # 10 x 7 tiles, ragged right and bottom edges
+    tiles_x = (90 - 13 + 7) // 8
+    for count in (1, 2, 3, 8, 100):
+        cover = np.zeros((60, 90), int)
+        for r in range(count):
+            for (x0, y0, x1, y1) in zd.shard_tiles(rect, r, count):
+                cover[y0:y1, x0:x1] += 1
+                tx, ty = (x0 - 13) // 8, (y0 - 7) // 8
+                assert (ty * tiles_x + ((tx - ty) % tiles_x if count > 1 else tx)) % count == r
+        assert (cover[7:60, 13:90] == 1).all() and cover.sum() == (60 - 7) * (90 - 13)
+    # eight shards of a 128-tile-wide image: a shard's tiles do not line up in columns
+    cols = {x0 for (x0, y0, x1, y1) in zd.shard_tiles((0, 0, 1024, 64), 0, 8)}
+    assert len(cols) > 16
 
 
 def test_shard_plans_cover_the_work_exactly():

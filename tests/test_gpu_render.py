@@ -144,6 +144,10 @@ def test_interleaved_tile_shards_union(integrator, accel, count, mat_a):
         ty, tx = torch.meshgrid(torch.arange(H, device="cuda") // 8, torch.arange(W, device="cuda") // 8, indexing="ij")
         tiles_x = (W + 7) // 8                                    # zdr.h: row ty is numbered from column ty on -> a shard's tiles run along diagonals
         assert torch.equal(mine, (ty * tiles_x + (tx - ty) % tiles_x) % count == r)
+        from zdr_amd import distributed as zd                     # the host-side mirror the gloo tests and rehearsals use
+        host = torch.zeros((H, W), dtype=torch.bool)
+        for (x0, y0, x1, y1) in zd.shard_tiles((0, 0, W, H), r, count): host[y0:y1, x0:x1] = True
+        assert torch.equal(mine.cpu(), host)
     assert (owner == 1).all() and torch.equal(parts, full)
     cot = torch.from_numpy(np.random.default_rng(2).uniform(0.5, 1.5, (H, W, 4)).astype(np.float32)).cuda()
     g_full = torch.zeros_like(m); g_parts = torch.zeros_like(m)
@@ -154,6 +158,24 @@ def test_interleaved_tile_shards_union(integrator, accel, count, mat_a):
         for k, v in scene.render_stats(m, (W, H), spp, 6, tile_shard=(r, count)).items(): stats[k] = stats.get(k, 0) + v
     torch.testing.assert_close(g_parts, g_full, rtol=1e-4, atol=1e-6 * float(g_full.abs().max()))
     assert stats == scene.render_stats(m, (W, H), spp, 6)
+
+
+def test_a_shard_without_tiles_leaves_no_stale_tile_masks(mat_a):
+    """More shards than tiles: the last shard owns nothing and launches nothing — in particular not k_tile_masks.  The
+    handle must not remember masks it never built (the next call on the same view would have read a
+    freshly allocated, uninitialised mask buffer and silently skipped primitives)."""
+    m = torch.from_numpy(mat_a).cuda()
+    W, H, spp = 24, 16, 8                                        # 3 x 2 = 6 tiles
+    want = make_scene("path").render_forward(m, (W, H), spp, 5, tile_shard=(0, 7))
+    scene = make_scene("path")                                   # a fresh handle: its mask buffer does not exist yet
+    empty = scene.render_forward(m, (W, H), spp, 5, tile_shard=(6, 7))
+    assert (empty == 0).all()
+    g = torch.zeros_like(m)
+    scene.render_backward(torch.ones((H, W, 4), device="cuda"), g, m, (W, H), spp, 5, tile_shard=(6, 7))
+    assert (g == 0).all()
+    got = scene.render_forward(m, (W, H), spp, 5, tile_shard=(0, 7))
+    assert torch.equal(got, want)
+    scene.check()
 
 
 def test_tile_shards_inside_a_rectangle_and_for_uvgrad(mat_a):

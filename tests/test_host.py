@@ -24,9 +24,23 @@ def test_library_exports_every_symbol_of_the_header():
 
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_native.CameraPOD) == 40
-    assert C.sizeof(_native.RenderParams) == 4 * 15 + 40 + 8 + 12
-    assert _native.RenderParams.camera.offset == 60 and _native.RenderParams.tex_h.offset == 100 and _native.RenderParams.tile_shard_count.offset == 112
+    assert C.sizeof(_native.RenderParams) == 4 * 16 + 40 + 8 + 12
+    assert _native.RenderParams.struct_size.offset == 0
+    assert _native.RenderParams.camera.offset == 64 and _native.RenderParams.tex_h.offset == 104 and _native.RenderParams.tile_shard_count.offset == 116
     assert C.sizeof(_native.SceneInfo) == 48
+
+
+def test_abi_version_and_struct_size_are_checked():
+    """A stub built against another revision of include/zdr.h is refused, not read past."""
+    L = _native.lib()
+    hdr = open(os.path.join(ROOT, "include", "zdr.h")).read()
+    assert L.zdr_abi_version() == _native.ABI_VERSION == int(re.search(r"#define ZDR_ABI_VERSION (\d+)", hdr).group(1))
+    p = _native.RenderParams()
+    p.struct_size = C.sizeof(_native.RenderParams) - 12          # the round-1 struct, three fields short
+    cnt = (C.c_uint64 * 8)()
+    fake = C.c_void_p(16)                                        # never dereferenced: the check comes first
+    rc = L.zdr_path_dump(fake, C.byref(p), fake, None, fake, 1, 1, fake, None)
+    assert rc == -1 and b"struct_size" in L.zdr_last_error()
 
 
 def test_no_silent_cpu_fallback():

@@ -47,3 +47,17 @@ def test_the_fma_build_flips_few_paths_and_agrees_on_the_rest(cbox_arrays, cbox_
     # light-sample acceptance test (prb.py:62) is a coin toss there — with zero radiance at stake (path_trace.Trace.decisions)
     raw = (a.nvert != b.nvert) | np.any((a.flags != b.flags) & a.live & b.live, axis=1)
     assert raw.mean() > 5 * max(st["flipped"], 1) / a.n
+
+
+def test_queries_outside_the_image_or_sample_range_read_as_zero_rows(cbox_oracle):
+    """The twin of zdr_path_dump's guard (include/zdr.h): a query whose pixel lies outside the image or whose
+    sample_index >= spp yields an all-zero row — also with a cotangent image, which must not be read out of bounds."""
+    mat = fd_material_np(64, 0)
+    W, H, spp = 16, 12, 4
+    p = oracle.make_params("path", W, H, spp, 7, CBOX_CAMERA, mat.shape[:2])
+    q = np.array([[3, 4, 1], [-1, 4, 1], [3, -2, 0], [W, 4, 1], [3, H, 1], [3, 4, spp], [3, 4, spp + 100], [W - 1, H - 1, spp - 1]], np.int32)
+    cot = np.ones((H, W, 4), np.float32)
+    for d_image in (None, cot):
+        out = cbox_oracle.path_dump(p, mat, q, d_image=d_image)
+        assert out[0].view(np.int32)[0] > 0 and out[7].view(np.int32)[0] >= 0
+        assert (out[1:7] == 0).all()

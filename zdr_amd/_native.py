@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libzdr_hip.so")
 COLLOCATED, DIRECT, PATH, UVGRAD = 0, 1, 2, 3
 SAMPLER_CMJ, SAMPLER_PMJ02BN = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
+ABI_VERSION = 3                # ZDR_ABI_VERSION of the include/zdr.h this binding mirrors
 PRB_MODES = {"expectation": 0, "detached": 1}
 INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH}   # render.py:65-69
 SAMPLERS = {"cmj": SAMPLER_CMJ, "corrmj": SAMPLER_CMJ, "pmj02bn": SAMPLER_PMJ02BN}
@@ -22,7 +23,7 @@ COUNTER_NAMES = ("samples", "closest_rays", "closest_hits", "shadow_rays", "shad
                  "emitter_hits_bsdf", "nan_samples", "shadow_rays_traced")
 
 # every symbol include/zdr.h declares
-EXPORTS = ("zdr_version", "zdr_last_error", "zdr_scene_create", "zdr_scene_destroy", "zdr_scene_info",
+EXPORTS = ("zdr_version", "zdr_abi_version", "zdr_last_error", "zdr_scene_create", "zdr_scene_destroy", "zdr_scene_info",
            "zdr_scene_set_emissions", "zdr_scene_set_envmap", "zdr_scene_set_pmj02bn_tables", "zdr_render_forward", "zdr_render_backward",
            "zdr_render_stats", "zdr_scene_check", "zdr_trace_closest", "zdr_trace_any", "zdr_sampler_dump", "zdr_path_dump", "zdr_debug_build_accel")
 
@@ -33,7 +34,7 @@ class CameraPOD(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [
-        ("integrator", C.c_int32), ("sampler", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("struct_size", C.c_uint32), ("integrator", C.c_int32), ("sampler", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
         ("spp", C.c_uint32), ("seed", C.c_uint32), ("use_tent", C.c_int32),
         ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
         ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
@@ -87,6 +88,8 @@ def lib():
     L.zdr_debug_build_accel.argtypes = [fp, C.c_uint32, C.c_int, fp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), ip, fp]
     for name in EXPORTS:
         getattr(L, name)          # AttributeError here = header and library disagree
+    if L.zdr_abi_version() != ABI_VERSION:
+        raise ZdrError(f"{LIB_PATH} speaks ABI {L.zdr_abi_version()}, this binding ABI {ABI_VERSION}: rebuild (python -m zdr_amd.build --force)")
     _LIB = L
     return L
 

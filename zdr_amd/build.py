@@ -30,6 +30,19 @@ def _sources():
         os.path.join(ROOT, "include", "zdr.h")]
 
 
+def source_hash() -> str:
+    """sha256 over the kernel / host sources and the header, in name order: identifies the code a profile was taken on
+    (profiles/pmc_traffic.json carries it; bench.py marks counter figures stale when it differs).  Works without git —
+    the GPU box receives a snapshot, not a repository."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in _sources():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True

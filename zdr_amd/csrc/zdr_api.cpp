@@ -18,6 +18,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ZDR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 extern "C" const char *zdr_version(void) { return ZDR_VERSION_STRING; }
+extern "C" int zdr_abi_version(void) { return ZDR_ABI_VERSION; }
 extern "C" const char *zdr_last_error(void) { return g_err.c_str(); }
 
 // ------------------------------------------------------------------------------ host vec3
@@ -736,7 +737,17 @@ static int make_sampler_cfg(const zdr_scene *s, int32_t sampler, uint32_t seed, 
     return ZDR_OK;
 }
 
+// The struct grows with the library: a caller built against another header says so in struct_size instead of having the
+// library read past (or short of) what it passed.  Checked before anything else looks at the parameters.
+static int check_params_abi(const zdr_render_params *p) {
+    if (p->struct_size != sizeof(zdr_render_params))
+        return fail(ZDR_E_INVALID, "zdr_render_params.struct_size is " + std::to_string(p->struct_size) + ", this library (ABI " + std::to_string(ZDR_ABI_VERSION) +
+                                   ") expects " + std::to_string(sizeof(zdr_render_params)) + ": caller and library were built from different include/zdr.h");
+    return ZDR_OK;
+}
+
 static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg &R) {
+    { int rc = check_params_abi(p); if (rc) return rc; }
     if (p->integrator < 0 || p->integrator > ZDR_UVGRAD) return fail(ZDR_E_INVALID, "unknown integrator");
     if (p->integrator == ZDR_UVGRAD && backward) return fail(ZDR_E_UNSUPPORTED, "render_duvdxy has no backward pass");
     if (p->width <= 0 || p->height <= 0) return fail(ZDR_E_INVALID, "bad resolution");
@@ -855,9 +866,10 @@ extern "C" int zdr_scene_check(zdr_scene *s, void *stream) {
 static int render_common(zdr_scene *s, const zdr_render_params *p, const float *material, float *image, const float *d_image,
                          float *d_material, int backward, int stats, void *stream) {
     if (!s || !p || !material) return fail(ZDR_E_INVALID, "null argument");
+    int rc = check_params_abi(p); if (rc) return rc;
     HIPCHK(hipSetDevice(s->device));
     RenderCfg R; SamplerCfg C;
-    int rc = make_render_cfg(p, backward != 0, R); if (rc) return rc;
+    rc = make_render_cfg(p, backward != 0, R); if (rc) return rc;
     rc = make_sampler_cfg(s, p->sampler, p->seed, p->spp, C); if (rc) return rc;
     if (backward) { rc = ensure_cells(s, R, (hipStream_t)stream); if (rc) return rc; }
     else if (!stats) { rc = ensure_partial(s, R); if (rc) return rc; }
@@ -883,7 +895,9 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
                          R.cam_o[0], R.cam_o[1], R.cam_o[2], R.cam_fwd[0], R.cam_fwd[1], R.cam_fwd[2], R.cam_right[0], R.cam_right[1], R.cam_right[2],
                          R.cam_upp[0], R.cam_upp[1], R.cam_upp[2], (float)R.tiles_x, (float)R.tiles_y};
         io.tile_masks_valid = (s->tile_mask_key_set && memcmp(key, s->tile_mask_key, sizeof key) == 0) ? 1 : 0;
-        memcpy(s->tile_mask_key, key, sizeof key); s->tile_mask_key_set = true;
+        // the key is recorded only when k_tile_masks is really going to run: a shard that owns no tile (more shards than
+        // tiles) launches nothing, and must not leave the key of masks nobody built behind for the next call
+        if ((long)R.ntiles * R.nchunks > 0) { memcpy(s->tile_mask_key, key, sizeof key); s->tile_mask_key_set = true; }
     }
     io.material = (const float4 *)material; io.image = (float4 *)image; io.partial = s->d_partial;
     io.d_image = (const float4 *)d_image; io.d_material = d_material; io.cells = s->d_cells; io.counters = s->d_counters;
@@ -942,6 +956,7 @@ extern "C" int zdr_trace_any(zdr_scene *s, const float *rays, uint32_t n, int32_
 extern "C" int zdr_path_dump(zdr_scene *s, const zdr_render_params *p, const float *material, const float *d_image,
                              const int32_t *queries, uint32_t n, int32_t maxv, float *out, void *stream) {
     if (!s || !p || !material || !queries || !out) return fail(ZDR_E_INVALID, "null argument");
+    if (int rc = check_params_abi(p)) return rc;
     if (p->integrator != ZDR_PATH) return fail(ZDR_E_UNSUPPORTED, "path traces exist for the path integrator only");
     if (maxv < 1 || maxv > ZDR_MAX_RECORDED_DEPTH) return fail(ZDR_E_INVALID, "maxv must lie in [1, 16]");
     HIPCHK(hipSetDevice(s->device));

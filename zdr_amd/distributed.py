@@ -54,12 +54,29 @@ def plan(mode: str, rank: int, world: int, res, spp: int, seed: int) -> Shard:
     raise KeyError(mode)
 
 
+def shard_tiles(rect, index: int, count: int) -> List[Tuple[int, int, int, int]]:
+    """The 8x8 tiles (as pixel rectangles) that tile shard (index, count) of ``rect`` owns, in launch order — the
+    numbering of include/zdr.h and decode_item (csrc/zdr_kernels.hip): tiles are numbered row by row from the rectangle's
+    own corner, row r starting at column r (mod the row length) when count > 1, and the shard owns the numbers
+    index, index + count, ...  Host-side mirror for tests and rehearsals; the kernels decode the same mapping themselves."""
+    x0, y0, x1, y1 = rect
+    tiles_x, tiles_y = (x1 - x0 + 7) // 8, (y1 - y0 + 7) // 8
+    skew = 1 if count > 1 else 0
+    out = []
+    for number in range(index if count > 1 else 0, tiles_x * tiles_y, max(count, 1)):
+        ty = number // tiles_x
+        tx = (number % tiles_x + ty * skew) % tiles_x
+        out.append((x0 + 8 * tx, y0 + 8 * ty, min(x0 + 8 * tx + 8, x1), min(y0 + 8 * ty + 8, y1)))
+    return out
+
+
 class ShardedRenderer:
     """local_forward(material, res, spp, seed, rect, samples, out, tile_shard) -> image (writes the shard into out)
     local_backward(grad_output, d_material, material, res, spp, seed, rect, samples, tile_shard) accumulates."""
 
     def __init__(self, local_forward: Callable, local_backward: Callable, mode: str = "tiles", group=None):
         self.local_forward, self.local_backward, self.mode, self.group = local_forward, local_backward, mode, group
+        self.reduce_events = None      # a list: time every exchange with HIP events (bench.py); None: don't
 
     @property
     def world(self) -> int:
@@ -69,19 +86,36 @@ class ShardedRenderer:
     def rank(self) -> int:
         return dist.get_rank(self.group) if dist.is_initialized() else 0
 
-    def _reduce(self, t: torch.Tensor, scale: float) -> torch.Tensor:
+    def _reduce(self, t: torch.Tensor, scale: float, what: str = "image") -> torch.Tensor:
+        """The one exchange step of a pass.  With ``reduce_events`` set, HIP events on the compute stream bracket it: a
+        synchronous collective makes the compute stream wait for the communicator's stream, so the pair measures the
+        all-reduce including the wait for the slowest rank."""
         if self.world > 1:
+            timed = self.reduce_events is not None and t.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if timed:
+                e1.record()
+                self.reduce_events.append((what, e0, e1))
         if scale != 1.0:
             t.mul_(scale)
         return t
+
+    def reduce_ms(self) -> dict:
+        """Total milliseconds the recorded exchanges took, by kind (call after a synchronise)."""
+        out = {"image": 0.0, "gradient": 0.0}
+        for what, e0, e1 in self.reduce_events or []:
+            out[what] += e0.elapsed_time(e1)
+        return out
 
     def forward(self, material, res, spp, seed):
         sh = plan(self.mode, self.rank, self.world, res, spp, seed)
         image = torch.zeros((res[1], res[0], 4), dtype=torch.float32, device=material.device)
         for rect in sh.rects:
             self.local_forward(material, res, spp, sh.seed, rect, sh.samples, image, sh.tile_shard)
-        return self._reduce(image, sh.scale)
+        return self._reduce(image, sh.scale, "image")
 
     def backward(self, grad_output, material, res, spp, seed):
         # grad_output is the cotangent of the REDUCED image and is identical on every rank
@@ -89,7 +123,7 @@ class ShardedRenderer:
         d_material = torch.zeros_like(material)
         for rect in sh.rects:
             self.local_backward(grad_output, d_material, material, res, spp, sh.seed, rect, sh.samples, sh.tile_shard)
-        return self._reduce(d_material, sh.scale)
+        return self._reduce(d_material, sh.scale, "gradient")
 
     def render(self, material, *, res, spp, seed=0):
         return _ShardedOp.apply(material, self, tuple(res), int(spp), int(seed))

@@ -131,6 +131,7 @@ class Scene:
             from . import pmj02bn_tables
             self.set_pmj02bn_tables(*pmj02bn_tables.default_tables(verbose=True))
         p = N.RenderParams()
+        p.struct_size = C.sizeof(N.RenderParams)
         p.integrator, p.sampler = self._integrator if integrator is None else integrator, N.SAMPLERS[self.sampler]
         p.width, p.height = int(res[0]), int(res[1])
         p.spp, p.seed = int(spp), int(seed) & 0xFFFFFFFF            # seeds are uint32 (App. B-15)

@@ -137,7 +137,7 @@ def test_environment_and_pmj02bn_tables_are_independent_state(cbox_arrays, sky_t
     either order, and each buffer is released exactly once (its setter or zdr_scene_destroy)."""
     import ctypes as C
     import torch
-    from gpu_util import assert_grad_parity, assert_image_parity, make_scene, oracle_params
+    from gpu_util import Flips, assert_grad_parity, assert_image_parity, make_scene, oracle_params
     from zdr_amd import pmj02bn_tables as T
     I, prob, alias, pdf = sky_tables
     pmj = T.pmj02_sets(n_sets=5, n_samples=256, seed=2)
@@ -164,9 +164,11 @@ def test_environment_and_pmj02bn_tables_are_independent_state(cbox_arrays, sky_t
         p = oracle_params(scene, W, W, spp, 4, mat.shape[:2], sampler=oracle.SAMPLER_PMJ02BN)
         pb = oracle_params(scene, W, W, spp, 5, mat.shape[:2], sampler=oracle.SAMPLER_PMJ02BN)
         assert_image_parity(img.detach().cpu().numpy()[..., :3], S.render_forward(p, mat)[..., :3], f"envmap + pmj02bn forward ({order})",
-                            floor=Sf.render_forward(p, mat)[..., :3], n_paths=W * W * spp)
+                            floor=Sf.render_forward(p, mat)[..., :3],
+                            flips=Flips(scene, S, Sf, mat, (W, W), spp, 4, what=f"envmap + pmj02bn forward ({order})", sampler=oracle.SAMPLER_PMJ02BN))
         assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, ones, mat), f"envmap + pmj02bn backward ({order})",
-                           floor=Sf.render_backward(pb, ones, mat), n_paths=W * W * spp)
+                           floor=Sf.render_backward(pb, ones, mat),
+                           flips=Flips(scene, S, Sf, mat, (W, W), spp, 5, cot=ones, what=f"envmap + pmj02bn backward ({order})", sampler=oracle.SAMPLER_PMJ02BN))
         # new tables while an environment is set, then render again: the environment is still there
         scene.set_pmj02bn_tables(pmj, bn)
         again = scene.render(m.detach(), res=(W, W), spp=spp, seed=4)

@@ -8,7 +8,7 @@ import torch
 
 import oracle
 from conftest import cbox_material_np, cbox_models, fd_material_np
-from gpu_util import assert_grad_parity, assert_image_parity, make_scene, oracle_params, random_rays
+from gpu_util import Flips, assert_grad_parity, assert_image_parity, make_scene, oracle_params, random_rays
 from path_trace import Trace, all_queries, deviation_percentiles, image_from_paths, scatter_gradients
 from test_gpu_fd import directional
 
@@ -70,18 +70,22 @@ def test_forward_and_backward_match_the_oracle(material, million):
         assert st["flipped"] <= 2 * fl["flipped"] + 5, (st, fl)
         for key in ("L", "grad"):
             assert st[key][50] <= max(2e-5, 2 * fl[key][50]) and st[key][90] <= max(1e-3, 2 * fl[key][90]), (key, st, fl)
-    same = tr.signature_equal(rt)
     # the kernels' gradient texture is the scatter of the traced vertex gradients
     tg = scatter_gradients(tr, *mat.shape[:2])
     g = m.grad.cpu().numpy()
     assert np.abs(tg - g).sum() <= 2e-4 * np.abs(tg).sum()
-    # image and gradient as a whole: each flipped path may move its own pixel / texels
-    flips = int((~same).sum())
-    bad_px = (np.abs(img.detach().cpu().numpy()[..., :3] - ref[..., :3]) > 1e-4 * (1 + np.abs(ref[..., :3]))).any(axis=2).sum()
-    if material == "A":
-        assert bad_px <= flips + 2, (bad_px, flips)
-        assert_grad_parity(g, gref, "1M triangles backward", n_paths=n)
-    # material B: the per-path comparison above is the statement; whole-image statistics of 576 pixels say nothing more
+    # Image and gradient as a whole, BOTH materials: the paths that measurably took another branch than the oracle's are
+    # set aside (their pixels / texel footprints), everything else meets the bars — for the glossy material the bars
+    # calibrated by the oracle's own FMA build, as everywhere (gpu_util.assert_image_parity).
+    pb = oracle_params(scene, W, H, spp, seed + 1, mat.shape[:2])
+    fma_b = Trace(Sf.path_dump(pb, mat, q, d_image=cot))
+    fb = Flips(scene, S, Sf, mat, (W, H), spp, seed + 1, cot=cot, what=f"1M triangles backward {material}", traces=(tr, rt, fma_b))
+    ff = Flips(scene, S, Sf, mat, (W, H), spp, seed, what=f"1M triangles forward {material}")
+    pf = oracle_params(scene, W, H, spp, seed, mat.shape[:2])
+    glossy = material == "B"
+    assert_image_parity(img.detach().cpu().numpy()[..., :3], ref[..., :3], f"1M triangles forward {material}", flips=ff,
+                        floor=Sf.render_forward(pf, mat)[..., :3] if glossy else None)
+    assert_grad_parity(g, gref, f"1M triangles backward {material}", flips=fb, floor=Sf.render_backward(pb, cot, mat) if glossy else None)
 
 
 def test_ad_matches_fd_on_the_million_triangle_scene(million):

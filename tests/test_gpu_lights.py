@@ -7,7 +7,7 @@ import torch
 
 import oracle
 from conftest import cbox_material_np, fd_material_np
-from gpu_util import assert_grad_parity, assert_image_parity, make_scene, multi_light_arrays, oracle_params
+from gpu_util import Flips, assert_grad_parity, assert_image_parity, make_scene, multi_light_arrays, oracle_params
 
 pytestmark = pytest.mark.gpu
 
@@ -48,22 +48,24 @@ def test_three_lights_glossy_material(stage):
     img = scene.render(m, res=(W, W), spp=spp, seed=seed)
     p = oracle_params(scene, W, W, spp, seed, mat.shape[:2])
     assert_image_parity(img.detach().cpu().numpy()[..., :3], S.render_forward(p, mat)[..., :3], "three lights glossy forward",
-                        floor=Sf.render_forward(p, mat)[..., :3], n_paths=W * W * spp)
+                        floor=Sf.render_forward(p, mat)[..., :3], flips=Flips(scene, S, Sf, mat, (W, W), spp, seed, what="three lights glossy forward"))
     img.sum().backward()
     pb = oracle_params(scene, W, W, spp, seed + 1, mat.shape[:2]); ones = np.ones((W, W, 4), np.float32)
     assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, ones, mat), "three lights glossy backward",
-                       floor=Sf.render_backward(pb, ones, mat), n_paths=W * W * spp)
+                       floor=Sf.render_backward(pb, ones, mat), flips=Flips(scene, S, Sf, mat, (W, W), spp, seed + 1, cot=ones, what="three lights glossy backward"))
 
 
 @pytest.mark.parametrize("integrator", ["direct", "path"])
 def test_update_lights_against_the_oracle(integrator, stage):
     """Light-stage switching: every step changes which instances emit (and so light_count, the light list and the
     flat light table) and is compared with the oracle's set_emissions — forward and backward."""
-    A, S, _ = stage
+    A, S, Sf = stage
     scene = make_scene(integrator, arrays=A)
     mat = cbox_material_np()
     m = torch.from_numpy(mat).cuda()
     W, spp = 64, 16
+    # the paths that take another branch than the oracle's are MEASURED per step (path integrator: the dump exists for it alone)
+    flips = (lambda seed, cot, what: Flips(scene, S, Sf, mat, (W, W), spp, seed, cot=cot, what=what)) if integrator == "path" else (lambda *a: None)
     ones = np.ones((W, W, 4), np.float32)
     steps = [
         [None, 20.0, None, None, None],                          # the ceiling light alone: light_count 1 (light0_T short cut)
@@ -76,7 +78,7 @@ def test_update_lights_against_the_oracle(integrator, stage):
     for k, em in enumerate(steps):
         scene.update_lights(em)
         e = np.stack([np.zeros(3) if x is None else np.broadcast_to(np.asarray(x, np.float32), (3,)) for x in em]).astype(np.float32)
-        S.set_emissions(e)
+        S.set_emissions(e); Sf.set_emissions(e)
         n = int((e > 0).any(axis=1).sum())
         assert scene.info()["light_count"] == n == scene.light_count
         img = scene.render_forward(m, (W, W), spp, 20 + k).cpu().numpy()
@@ -84,17 +86,17 @@ def test_update_lights_against_the_oracle(integrator, stage):
         if n == 0:
             assert img[..., :3].max() == 0.0 and ref[..., :3].max() == 0.0
             continue
-        assert_image_parity(img[..., :3], ref[..., :3], f"update_lights step {k} {integrator} forward", n_paths=W * W * spp)
+        assert_image_parity(img[..., :3], ref[..., :3], f"update_lights step {k} {integrator} forward", flips=flips(20 + k, None, f"update_lights step {k} forward"))
         g = torch.zeros_like(m)
         scene.render_backward(torch.from_numpy(ones).cuda(), g, m, (W, W), spp, 20 + k)
         gref = S.render_backward(oracle_params(scene, W, W, spp, 21 + k, mat.shape[:2]), ones, mat)
-        assert_grad_parity(g.cpu().numpy(), gref, f"update_lights step {k} {integrator} backward", n_paths=W * W * spp)
-    S.set_emissions(A.inst_emission)
+        assert_grad_parity(g.cpu().numpy(), gref, f"update_lights step {k} {integrator} backward", flips=flips(21 + k, ones, f"update_lights step {k} backward"))
+    S.set_emissions(A.inst_emission); Sf.set_emissions(A.inst_emission)
 
 
 def test_backward_replays_the_emission_snapshot_of_its_forward(stage):
     """render.py:216-222: backward re-uploads the emissions the forward saw (the scene stays at the snapshot)."""
-    A, S, _ = stage
+    A, S, Sf = stage
     scene = make_scene("path", arrays=A)
     mat = cbox_material_np()
     m = torch.from_numpy(mat).cuda().requires_grad_()
@@ -104,8 +106,10 @@ def test_backward_replays_the_emission_snapshot_of_its_forward(stage):
     scene.update_lights([None, None, None, None, 9.0])           # changed between forward and backward
     img.sum().backward()
     e = np.zeros((5, 3), np.float32); e[1] = 20.0; e[2] = (6.0, 2.0, 1.0)
-    S.set_emissions(e)
-    gref = S.render_backward(oracle_params(scene, 48, 48, 16, 3, mat.shape[:2]), np.ones((48, 48, 4), np.float32), mat)
-    assert_grad_parity(m.grad.cpu().numpy(), gref, "backward under the forward's emission snapshot", n_paths=48 * 48 * 16)
-    assert scene.emissions is first
-    S.set_emissions(A.inst_emission)
+    S.set_emissions(e); Sf.set_emissions(e)
+    ones = np.ones((48, 48, 4), np.float32)
+    gref = S.render_backward(oracle_params(scene, 48, 48, 16, 3, mat.shape[:2]), ones, mat)
+    assert scene.emissions is first                              # the scene was left at the forward's snapshot: the dump below sees the same lights
+    assert_grad_parity(m.grad.cpu().numpy(), gref, "backward under the forward's emission snapshot",
+                       flips=Flips(scene, S, Sf, mat, (48, 48), 16, 3, cot=ones, what="emission snapshot backward"))
+    S.set_emissions(A.inst_emission); Sf.set_emissions(A.inst_emission)

@@ -7,7 +7,7 @@ import torch
 import oracle
 from conftest import CBOX_CAMERA, cbox_material_np, fd_material_np
 from zdr_amd.mathtypes import Camera, float3
-from gpu_util import (TERRAIN_CAMERA, assert_grad_parity, assert_image_parity, make_scene, oracle_params, terrain_arrays)
+from gpu_util import (TERRAIN_CAMERA, Flips, assert_grad_parity, assert_image_parity, make_scene, oracle_params, terrain_arrays)
 
 pytestmark = pytest.mark.gpu
 
@@ -371,11 +371,13 @@ def test_instance_transforms(mat_b):
     p = oracle_params(scene, W, W, spp, 3, mat_b.shape[:2])
     ref = S.render_forward(p, mat_b)
     assert ref[..., :3].mean() > 0.02
-    assert_image_parity(img.detach().cpu().numpy()[..., :3], ref[..., :3], "transformed instances forward", floor=Sf.render_forward(p, mat_b)[..., :3], n_paths=W * W * spp)
+    assert_image_parity(img.detach().cpu().numpy()[..., :3], ref[..., :3], "transformed instances forward", floor=Sf.render_forward(p, mat_b)[..., :3],
+                        flips=Flips(scene, S, Sf, mat_b, (W, W), spp, 3, what="transformed instances forward"))
     img.sum().backward()
     pb = oracle_params(scene, W, W, spp, 4, mat_b.shape[:2])
     ones = np.ones((W, W, 4), np.float32)
-    assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, ones, mat_b), "transformed instances backward", floor=Sf.render_backward(pb, ones, mat_b), n_paths=W * W * spp)
+    assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, ones, mat_b), "transformed instances backward", floor=Sf.render_backward(pb, ones, mat_b),
+                       flips=Flips(scene, S, Sf, mat_b, (W, W), spp, 4, cot=ones, what="transformed instances backward"))
 
 
 def test_render_duvdxy_matches_oracle(cbox_oracle, mat_a):
@@ -423,7 +425,7 @@ def test_a_tripped_watchdog_is_reported_not_swallowed(mat_a, monkeypatch):
 
 @pytest.mark.parametrize("tex", [(1, 1), (2, 2), (4, 4), (5, 3), (8, 8), (16, 16), (40, 24)])
 @pytest.mark.parametrize("integrator", ["path", "direct"])
-def test_few_texels_gradient_matches_oracle(tex, integrator, cbox_oracle):
+def test_few_texels_gradient_matches_oracle(tex, integrator, cbox_oracle, cbox_oracle_fma):
     """README.md:21 of the reference: gradients that concentrate on few texels.  The kernels then keep the whole
     staging-cell array in LDS (<= 28 cells) or add into replicated cell arrays (scene.h); both are re-associations of
     the same sum.  (tex_h, tex_w) from a constant material (1 x 1) over non-square ones; float32 accumulators that
@@ -446,7 +448,8 @@ def test_few_texels_gradient_matches_oracle(tex, integrator, cbox_oracle):
         bad = np.abs(got - ref) > 2e-3 * np.abs(ref) + 2e-4 * np.abs(ref).max()
         assert bad.sum() == 0, (int(bad.sum()), np.abs(got - ref).max())
     else:
-        assert_grad_parity(got, ref, f"few texels {th}x{tw} {integrator}", n_paths=W * W * spp)
+        assert_grad_parity(got, ref, f"few texels {th}x{tw} {integrator}",
+                           flips=Flips(scene, cbox_oracle, cbox_oracle_fma, mat, (W, W), spp, seed + 1, cot=cot, what=f"few texels {th}x{tw}") if integrator == "path" else None)
     assert abs(got.sum() - ref.sum()) <= 3e-4 * abs(ref.sum())
 
 
@@ -464,7 +467,8 @@ def test_detached_adjoint_mode_matches_oracle(accel, cbox_oracle, cbox_oracle_fm
     scene.render_backward(torch.from_numpy(cot).cuda(), g, m, (W, W), spp, seed)
     p = oracle_params(scene, W, W, spp, seed + 1, mat_b.shape[:2], prb_mode=oracle.PRB_DETACHED)
     ref = cbox_oracle.render_backward(p, cot, mat_b)
-    assert_grad_parity(g.cpu().numpy(), ref, f"detached adjoint / {accel}", floor=cbox_oracle_fma.render_backward(p, cot, mat_b), n_paths=W * W * spp)
+    assert_grad_parity(g.cpu().numpy(), ref, f"detached adjoint / {accel}", floor=cbox_oracle_fma.render_backward(p, cot, mat_b),
+                       flips=Flips(scene, cbox_oracle, cbox_oracle_fma, mat_b, (W, W), spp, seed + 1, cot=cot, what=f"detached adjoint / {accel}", prb_mode=oracle.PRB_DETACHED))
     scene.prb_mode = "expectation"
     g2 = torch.zeros_like(m)
     scene.render_backward(torch.from_numpy(cot).cuda(), g2, m, (W, W), spp, seed)

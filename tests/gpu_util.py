@@ -26,10 +26,28 @@ def image_diff_stats(got, ref):
     }
 
 
-# a whole-tensor sum is dominated by a few heavy-tailed paths: give it more head-room than the robust per-element
-# statistics.  Measured HIP / floor ratios of the robust statistics on renders of >= 64^2 pixels: 0.9 - 1.2 (round 2);
-# tests/test_gpu_paths.py makes the same comparison path by path.
-FLOOR_FACTORS = {"frac_bad": 1.5, "mean_rel": 1.5, "rel_l1": 1.5, "sum_rel": 6.0}
+# Glossy inputs: each robust statistic may reach FLOOR_FACTOR x what the oracle's own FMA and IEEE builds differ by.  MEASURED
+# (tools/glossy_floor.py, profiles/r3_glossy_floor_ratio.txt: 16 seeds x 4 scenes, flipped paths of all builds set aside): on renders
+# of 64^2 x 16 paths and more the ratio HIP-vs-IEEE / FMA-vs-IEEE has median 1.10 - 1.24, 90th percentile 1.12 - 1.54, maximum 1.65
+# — the HIP build perturbs more operations than FMA contraction alone (v_rcp / v_rsq / v_sqrt, device sin and cos at 1 - 2 ulp).
+# On renders of a few thousand paths the ratio of two such small numbers is noise (maximum 5.7): those sizes are compared path by
+# path instead (tests/test_golden.py, tests/test_gpu_paths.py).
+FLOOR_FACTOR = 2.0
+
+
+def _bound(key, base, fl, numel, mean_key):
+    """The bar for one statistic, `fl` = the same statistics of the FMA build of the oracle (glossy inputs) or None.
+    frac_bad is a COUNT of entries: a count of a handful fluctuates like a Poisson variable, so it is compared with the
+    allowed mean plus three standard deviations of a count with that mean (below 5 % of the bar from 10^5 entries on).
+    sum_rel: |sum(got - ref)| <= sum|got - ref|, so with a ruler the sum is held to the bar of the mean absolute error —
+    the ratio of two signed sums of heavy-tailed terms that mostly cancel says nothing."""
+    if key == "sum_rel":
+        return max(base, _bound(mean_key, 0.0, fl, numel, mean_key)) if fl else base
+    bound = max(base, FLOOR_FACTOR * fl[key]) if fl else base
+    if key == "frac_bad":
+        mean = bound * numel
+        bound = (mean + 3.0 * np.sqrt(mean)) / numel
+    return bound
 
 
 class Flips:
@@ -92,7 +110,7 @@ def assert_image_parity(got, ref, what, floor=None, frac_bad=2e-3, mean_rel=2e-5
     sqrt(1 - |p|^2) near the disk rim, the GGX denominator cancels like 1/alpha^2): two CORRECT
     float32 evaluations of the reference's formulas then drift apart by far more than the base bar even on paths that keep
     every decision.  `floor` = image of the SAME oracle source compiled with FMA contraction; when given, each bound
-    becomes max(base, FLOOR_FACTORS x what the two CPU builds differ by)."""
+    becomes max(base, FLOOR_FACTOR x what the two CPU builds differ by) — FLOOR_FACTOR is measured, see above."""
     got, ref = np.asarray(got), np.asarray(ref)
     if flips is not None:
         flips.check_count(what)
@@ -103,8 +121,7 @@ def assert_image_parity(got, ref, what, floor=None, frac_bad=2e-3, mean_rel=2e-5
     fl = image_diff_stats(floor, ref) if floor is not None else None
     print(f"[parity] {what}: {st}" + (f" | fp32 floor (oracle fma vs ieee): {fl}" if fl else ""))
     for key, base in (("frac_bad", frac_bad), ("mean_rel", mean_rel), ("sum_rel", sum_rel)):
-        bound = max(base, FLOOR_FACTORS[key] * fl[key]) if fl else base
-        assert st[key] <= bound, (what, key, st, fl)
+        assert st[key] <= _bound(key, base, fl, ref.size, "mean_rel"), (what, key, st, fl)
     return st
 
 
@@ -134,8 +151,7 @@ def assert_grad_parity(got, ref, what, floor=None, frac_bad=2e-3, rel_l1=2e-4, s
     fl = grad_diff_stats(floor, ref) if floor is not None else None
     print(f"[parity] {what}: {st}" + (f" | fp32 floor (oracle fma vs ieee): {fl}" if fl else ""))
     for key, base in (("frac_bad", frac_bad), ("rel_l1", rel_l1), ("sum_rel", sum_rel)):
-        bound = max(base, FLOOR_FACTORS[key] * fl[key]) if fl else base
-        assert st[key] <= bound, (what, key, st, fl)
+        assert st[key] <= _bound(key, base, fl, ref.size, "rel_l1"), (what, key, st, fl)
     return st
 
 

@@ -56,13 +56,40 @@ def test_hip_matches_golden(case, cbox_arrays):
     Sf = oracle.OracleScene.from_arrays(cbox_arrays, variant="fma")
     p = oracle.make_params(integ, W, W, spp, seed, CBOX_CAMERA, mat.shape[:2], use_tent=tent)
     pb = oracle.make_params(integ, W, W, spp, seed + 1, CBOX_CAMERA, mat.shape[:2], use_tent=tent)
-    # the paths that measurably took another branch than the oracle's (path integrator: the dump exists for it alone)
     S = oracle.OracleScene.from_arrays(cbox_arrays)
     ones = np.ones((W, W, 4), np.float32)
-    ff = Flips(scene, S, Sf, mat, (W, W), spp, seed, what="golden " + name) if integ == "path" else None
-    fb = Flips(scene, S, Sf, mat, (W, W), spp, seed + 1, cot=ones, what="golden grad " + name) if integ == "path" else None
-    assert_image_parity(img.detach().cpu().numpy()[..., :3], G[name + "/image"][..., :3], "golden " + name, floor=Sf.render_forward(p, mat)[..., :3], flips=ff)
-    assert_grad_parity(m.grad.cpu().numpy(), G[name + "/grad"], "golden grad " + name, floor=Sf.render_backward(pb, ones, mat), flips=fb)
+    got_img, got_grad = img.detach().cpu().numpy()[..., :3], m.grad.cpu().numpy()
+    if integ != "path":        # one or two vertices per sample: no flipped-path bookkeeping (the dump exists for the path integrator alone)
+        assert_image_parity(got_img, G[name + "/image"][..., :3], "golden " + name, floor=Sf.render_forward(p, mat)[..., :3])
+        assert_grad_parity(got_grad, G[name + "/grad"], "golden grad " + name, floor=Sf.render_backward(pb, ones, mat))
+        return
+    # the paths that measurably took another branch than the oracle's are set aside; the rest is held to the bars
+    ff = Flips(scene, S, Sf, mat, (W, W), spp, seed, what="golden " + name)
+    fb = Flips(scene, S, Sf, mat, (W, W), spp, seed + 1, cot=ones, what="golden grad " + name)
+    if W * W * spp >= 30000:
+        assert_image_parity(got_img, G[name + "/image"][..., :3], "golden " + name, floor=Sf.render_forward(p, mat)[..., :3], flips=ff)
+        assert_grad_parity(got_grad, G[name + "/grad"], "golden grad " + name, floor=Sf.render_backward(pb, ones, mat), flips=fb)
+    else:
+        # A few thousand glossy paths: whole-image statistics are a handful of heavy-tailed terms and their ratio to the FMA
+        # ruler is noise (profiles/r3_glossy_floor_ratio.txt).  Compared path by path instead: the traces add up to the golden
+        # image / gradient wherever no path flipped, and the typical path agrees to rounding.
+        from path_trace import all_queries, deviation_percentiles, image_from_paths, scatter_gradients
+        ff.check_count("golden " + name); fb.check_count("golden grad " + name)
+        q = all_queries(W, W, spp)
+        st = deviation_percentiles(fb.hip, fb.ref)
+        print(f"[paths] golden {name}: {st}")
+        fl = deviation_percentiles(fb.fma, fb.ref)                      # the same percentiles between the oracle's two builds
+        for key in ("L", "grad"):
+            assert st[key][50] <= 2e-5 and st[key][90] <= max(1e-3, 2 * fl[key][90]), (key, st, fl)
+        keep = ~ff.pixels
+        ti = image_from_paths(ff.ref, q, W, W, spp)                     # the oracle's traces ARE the golden image ...
+        assert np.abs(ti - G[name + "/image"][..., :3])[keep].max() <= 1e-5 * (1 + np.abs(ti).max())
+        hi = image_from_paths(ff.hip, q, W, W, spp)                     # ... and the kernels' traces are the kernels' image
+        assert np.abs(hi - got_img).max() <= 1e-5 * (1 + np.abs(hi).max())
+        keep = ~fb.texels
+        tg, hg = scatter_gradients(fb.ref, *mat.shape[:2]), scatter_gradients(fb.hip, *mat.shape[:2])
+        assert np.abs(tg - G[name + "/grad"])[keep].sum() <= 1e-4 * np.abs(tg).sum()
+        assert np.abs(hg - got_grad).sum() <= 2e-4 * np.abs(hg).sum()
 
 
 @pytest.mark.gpu

@@ -145,6 +145,9 @@ struct ScatterQueue {                // pointers into this wave's LDS block
     int copy_base;                   // first cell of this wave's copy of the staging array
     int ncells;                      // (tex_h + 1) x (tex_w + 1)
     float *lds_cells;                // != nullptr: the whole cell array lives here (ncells <= ZDR_LDS_CELLS)
+#ifdef ZDR_BWD_STATS
+    unsigned long long st_flushes, st_entries, st_dups;   // measurement build: flushes, entries flushed, entries whose cell an earlier entry of the same flush holds
+#endif
 };
 #define ZDR_SCATTER_LDS_FLOATS (7 * ZDR_SCATTER_CAP)
 static_assert(16 * ZDR_LDS_CELLS <= ZDR_SCATTER_LDS_FLOATS, "the LDS cell array aliases the queue's block");
@@ -154,6 +157,9 @@ ZD ScatterQueue scatter_queue_init(float *lds, int tex_h, int tex_w, int cell_co
     ScatterQueue q;
     q.cell = (int *)lds; q.g = lds + ZDR_SCATTER_CAP; q.ox = lds + 5 * ZDR_SCATTER_CAP; q.oy = lds + 6 * ZDR_SCATTER_CAP;
     q.count = 0;
+#ifdef ZDR_BWD_STATS
+    q.st_flushes = q.st_entries = q.st_dups = 0;
+#endif
     q.ncells = (tex_h + 1) * (tex_w + 1);
     q.copy_base = (int)(blockIdx.x % (unsigned)cell_copies) * q.ncells;
     q.lds_cells = (q.ncells <= ZDR_LDS_CELLS) ? lds : nullptr;
@@ -170,6 +176,13 @@ ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int lane = threadIdx.x & 63, sub = lane >> 4, j = lane & 15;
+#ifdef ZDR_BWD_STATS
+    if (q.count > 0) {
+        bool dup = false;
+        if (lane < q.count) for (int k = 0; k < lane; k++) dup = dup || (q.cell[k] == q.cell[lane]);
+        q.st_flushes++; q.st_entries += (unsigned long long)q.count; q.st_dups += (unsigned long long)__popcll(__ballot(dup));
+    }
+#endif
     for (int base = 0; base < q.count; base += 4) {
         int e = base + sub;
         if (e < q.count) {

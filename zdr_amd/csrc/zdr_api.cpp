@@ -923,7 +923,19 @@ extern "C" int zdr_render_forward(zdr_scene *s, const zdr_render_params *p, cons
 extern "C" int zdr_render_backward(zdr_scene *s, const zdr_render_params *p, const float *d_image, const float *material,
                                    float *d_material, void *stream) {
     if (!d_image || !d_material) return fail(ZDR_E_INVALID, "null gradient buffer");
+#ifdef ZDR_BWD_STATS   // measurement build (tools/bwd_stats.py): the path backward kernel counts its trips, sweep iterations and flushes
+    if (s) { (void)hipSetDevice(s->device); (void)hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream); }
+    int rc = render_common(s, p, material, nullptr, d_image, d_material, 1, 0, stream);
+    if (!rc) {
+        unsigned long long h[8];
+        (void)hipMemcpyAsync(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream); (void)hipStreamSynchronize((hipStream_t)stream);
+        fprintf(stderr, "[bwd stats] trips %llu shaded %llu finished %llu sweep_iterations %llu sweep_steps %llu flushes %llu entries %llu duplicate_cells %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    }
+    return rc;
+#else
     return render_common(s, p, material, nullptr, d_image, d_material, 1, 0, stream);
+#endif
 }
 
 extern "C" int zdr_render_stats(zdr_scene *s, const zdr_render_params *p, const float *material, uint64_t counters[8], void *stream) {

@@ -313,6 +313,9 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
     ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
     it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
     int stall = 0;
+#ifdef ZDR_BWD_STATS
+    unsigned long long st_trips = 0, st_shaded = 0, st_fin = 0, st_iters = 0, st_steps = 0;
+#endif
     for (;;) {
         bool progress = false;
         if (pq.tail - pq.head < (uint32_t)__popcll(__ballot(!alive))) {
@@ -391,8 +394,16 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             // trip (still in registers) and the record of the NEXT step is fetched before the current one is processed, so
             // that a scratch read (records beyond the LDS ones) is under way while the gradient is computed and queued.
             PackedVertex cur = plast;
-            while (__ballot(sw_k >= 0) != 0ull) {
+#ifdef ZDR_BWD_STATS   // measurement build (tools/bwd_stats.py): how full are the trips and the sweep iterations
+            st_trips++; st_shaded += (unsigned long long)__popcll(__ballot(alive || done));
+            st_fin += (unsigned long long)__popcll(__ballot(sw_k >= 0));
+#endif
+            int sweep_cap = (R.debug_no_scatter == 4) ? 2 : ((R.debug_no_scatter == 5) ? 1 : 64);   // timing-only ablations 4 / 5: the sweep loop cut after 2 / 1 iterations
+            while (__ballot(sw_k >= 0) != 0ull && sweep_cap-- > 0) {
                 const bool swp = sw_k >= 0;
+#ifdef ZDR_BWD_STATS
+                st_iters++; st_steps += (unsigned long long)__popcll(__ballot(swp));
+#endif
                 PackedVertex nxt = cur;
                 if (swp && sw_k >= 1) {
                     const int k = sw_k - 1;
@@ -417,6 +428,13 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
         if (stall > 4) { raise_device_error(S, ZDR_DEVERR_STALL); break; }   // cannot happen (every branch above makes progress); never spin on the GPU, never end silently
     }
     scatter_finish(q, io.cells);
+#ifdef ZDR_BWD_STATS
+    if (lane == 0) {
+        atomicAdd(io.counters + 0, st_trips); atomicAdd(io.counters + 1, st_shaded); atomicAdd(io.counters + 2, st_fin);
+        atomicAdd(io.counters + 3, st_iters); atomicAdd(io.counters + 4, st_steps);
+        atomicAdd(io.counters + 5, q.st_flushes); atomicAdd(io.counters + 6, q.st_entries); atomicAdd(io.counters + 7, q.st_dups);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------- direct / collocated

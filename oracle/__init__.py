@@ -80,6 +80,7 @@ def lib(variant: str = "ieee"):
         L.zdro_generate_ray.argtypes = [C.POINTER(Params), C.c_float, C.c_float, fp, fp]
         L.zdro_offset_ray_origin.argtypes = [fp, fp, fp]
         L.zdro_read_bsdf.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float, fp]
+        L.zdro_debug_force_brute.argtypes = [C.c_int]
         L.zdro_set_pmj02bn_tables.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
         _LIBS[variant] = L
     return _LIBS[variant]

@@ -67,9 +67,21 @@ struct zdro_scene {
     float *env_tex;     /* env_h x env_w x 4 */
     float *alias_prob; int32_t *alias_idx;   /* [map_h] marginal p(y), then map_h tables of map_w: p(x|y) */
     float *env_pdf;     /* map_h x map_w */
+    /* Search structure of the ORACLE's own ray queries (scenes above ZDRO_BVH_MIN_TRIS triangles): a plain binary BVH
+     * over the same plane records.  It changes WHICH triangles are tested, never the test or the answer: trace_closest
+     * returns the hit of smallest t and, among equal t, of smallest triangle index — exactly what the brute-force loop
+     * returns (tests/test_oracle_render.py compares the two bit for bit).  It exists so that the 1 M-triangle scene of
+     * BASELINE configs[4] can be checked at useful sizes and timed as a CPU baseline; it mirrors nothing of the
+     * reference (LuisaCompute's Accel is third-party) and nothing of the product's BVH4 (zdr_api.cpp). */
+    int nbvh; struct zdro_bnode *bvh; int32_t *bvh_tri;   /* nodes; triangle indices in leaf order */
 };
+struct zdro_bnode { float lo[3], hi[3]; int32_t left, count; };   /* count > 0: leaf over bvh_tri[left .. left + count); else children left, left + 1 */
+#define ZDRO_BVH_MIN_TRIS 256
+static int g_force_brute = 0;
+void zdro_debug_force_brute(int on) { g_force_brute = on; }
 
 static void tri_planes(const v3 *p, float *out);
+static void build_bvh(zdro_scene *s);
 
 static v3 xform_point(const float *m, v3 v) {
     /* (transform * float4(v, 1)).xyz — interaction.py:19-21 */
@@ -134,6 +146,7 @@ zdro_scene *zdro_scene_create(const float *verts, int nverts, const int32_t *tri
         }
     }
     rebuild_lights(s);
+    if (ntris > ZDRO_BVH_MIN_TRIS) build_bvh(s);
     return s;
 }
 
@@ -141,7 +154,7 @@ void zdro_scene_destroy(zdro_scene *s) {
     if (!s) return;
     free(s->verts); free(s->tris); free(s->tri_begin); free(s->xform); free(s->nmat);
     free(s->emission); free(s->light_insts); free(s->tri_inst); free(s->wp); free(s->planes);
-    free(s->env_tex); free(s->alias_prob); free(s->alias_idx); free(s->env_pdf); free(s);
+    free(s->env_tex); free(s->alias_prob); free(s->alias_idx); free(s->env_pdf); free(s->bvh); free(s->bvh_tri); free(s);
 }
 
 /* Scene.add_envmap / load_envmap (render.py:150-156, envmap.py:116-203): the tables come from the host
@@ -201,21 +214,142 @@ static inline int tri_intersect(const float *q, const ray_t *r, float tmax, floa
     return 1;
 }
 
-static hit_t trace_closest(const zdro_scene *s, const ray_t *r) {
-    hit_t h; h.inst = -1; h.prim = -1; h.u = h.v = 0; h.t = r->tmax;
-    for (int t = 0; t < s->ntris; t++) {
-        float tt, u, v;
-        if (tri_intersect(s->planes + 12 * (size_t)t, r, h.t, &tt, &u, &v)) {
-            h.t = tt; h.u = u; h.v = v; h.inst = s->tri_inst[t]; h.prim = t - s->tri_begin[h.inst];
+/* ---- the oracle's own search structure (see struct zdro_scene) ---- */
+typedef struct { float c[3]; int32_t tri; } bprim_t;
+static int g_sort_axis;
+static int cmp_prim(const void *a, const void *b) {
+    float x = ((const bprim_t *)a)->c[g_sort_axis], y = ((const bprim_t *)b)->c[g_sort_axis];
+    return (x > y) - (x < y);
+}
+static void tri_bounds(const zdro_scene *s, int t, float *lo, float *hi) {
+    for (int a = 0; a < 3; a++) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }
+    for (int k = 0; k < 3; k++) {
+        const v3 p = s->wp[3 * (size_t)t + k]; const float c[3] = {p.x, p.y, p.z};
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], c[a]); hi[a] = fmaxf(hi[a], c[a]); }
+    }
+}
+/* median split along the longest axis of the centroid bounds; leaves of <= 4 triangles; iterative (explicit work list) */
+static void build_bvh(zdro_scene *s) {
+    const int n = s->ntris;
+    bprim_t *pr = (bprim_t *)malloc(sizeof(bprim_t) * (size_t)n);
+    for (int t = 0; t < n; t++) {
+        float lo[3], hi[3]; tri_bounds(s, t, lo, hi);
+        for (int a = 0; a < 3; a++) pr[t].c[a] = 0.5f * (lo[a] + hi[a]);
+        pr[t].tri = t;
+    }
+    s->bvh = (struct zdro_bnode *)malloc(sizeof(struct zdro_bnode) * (size_t)(2 * n));
+    int (*work)[3] = (int (*)[3])malloc(sizeof(int[3]) * 128);   /* node, first, count */
+    int nw = 0, nn = 1;
+    work[nw][0] = 0; work[nw][1] = 0; work[nw][2] = n; nw++;
+    while (nw) {
+        nw--; const int node = work[nw][0], first = work[nw][1], count = work[nw][2];
+        struct zdro_bnode *b = &s->bvh[node];
+        if (count <= 4) { b->left = first; b->count = count; continue; }
+        float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int i = first; i < first + count; i++)
+            for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], pr[i].c[a]); chi[a] = fmaxf(chi[a], pr[i].c[a]); }
+        int ax = 0; if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1; if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+        g_sort_axis = ax;
+        qsort(pr + first, (size_t)count, sizeof(bprim_t), cmp_prim);
+        const int half = count / 2;
+        b->left = nn; b->count = 0;
+        work[nw][0] = nn; work[nw][1] = first; work[nw][2] = half; nw++;
+        work[nw][0] = nn + 1; work[nw][1] = first + half; work[nw][2] = count - half; nw++;
+        nn += 2;
+    }
+    free(work);
+    s->nbvh = nn;
+    s->bvh_tri = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    for (int i = 0; i < n; i++) s->bvh_tri[i] = pr[i].tri;
+    free(pr);
+    /* boxes bottom-up (children always have larger indices than their parent), padded so that the slab test below can
+     * never reject a ray that the plane-form triangle test accepts: the accepted hit point lies within rounding of the
+     * triangle, the pad is four orders of magnitude above float32 rounding of the scene's coordinates */
+    float ext = 0.0f;
+    for (size_t i = 0; i < 3 * (size_t)n; i++) ext = fmaxf(ext, fmaxf(fabsf(s->wp[i].x), fmaxf(fabsf(s->wp[i].y), fabsf(s->wp[i].z))));
+    const float pad = 1e-4f * (ext > 0.0f ? ext : 1.0f);
+    for (int node = nn - 1; node >= 0; node--) {
+        struct zdro_bnode *b = &s->bvh[node];
+        for (int a = 0; a < 3; a++) { b->lo[a] = 3.0e38f; b->hi[a] = -3.0e38f; }
+        if (b->count > 0) {
+            for (int i = b->left; i < b->left + b->count; i++) {
+                float lo[3], hi[3]; tri_bounds(s, s->bvh_tri[i], lo, hi);
+                for (int a = 0; a < 3; a++) { b->lo[a] = fminf(b->lo[a], lo[a] - pad); b->hi[a] = fmaxf(b->hi[a], hi[a] + pad); }
+            }
+        } else {
+            for (int c = 0; c < 2; c++)
+                for (int a = 0; a < 3; a++) { b->lo[a] = fminf(b->lo[a], s->bvh[b->left + c].lo[a]); b->hi[a] = fmaxf(b->hi[a], s->bvh[b->left + c].hi[a]); }
         }
     }
+}
+/* conservative slab test: the ray's [tmin, tmax] against the padded box; a NaN (0 * inf) never rejects */
+static inline int box_hit(const struct zdro_bnode *b, const ray_t *r, const float *inv, float tmax) {
+    float t0 = r->tmin, t1 = tmax;
+    const float o[3] = {r->o.x, r->o.y, r->o.z};
+    for (int a = 0; a < 3; a++) {
+        float ta = (b->lo[a] - o[a]) * inv[a], tb = (b->hi[a] - o[a]) * inv[a];
+        if (ta > tb) { float x = ta; ta = tb; tb = x; }
+        if (ta > t0) t0 = ta;                       /* comparisons with NaN are false: the axis is ignored */
+        if (tb * 1.0000005f < t1) t1 = tb * 1.0000005f;
+    }
+    return !(t0 > t1);
+}
+
+static hit_t trace_closest(const zdro_scene *s, const ray_t *r) {
+    hit_t h; h.inst = -1; h.prim = -1; h.u = h.v = 0; h.t = r->tmax;
+    if (!s->bvh || g_force_brute) {
+        for (int t = 0; t < s->ntris; t++) {
+            float tt, u, v;
+            if (tri_intersect(s->planes + 12 * (size_t)t, r, h.t, &tt, &u, &v)) {
+                h.t = tt; h.u = u; h.v = v; h.inst = s->tri_inst[t]; h.prim = t - s->tri_begin[h.inst];
+            }
+        }
+        return h;
+    }
+    /* same answer through the search structure: smallest t, and among equal t the smallest triangle index (= the first
+     * one the loop above would have kept) */
+    const float inv[3] = {1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z};
+    int stack[128], sp = 0, best = -1;
+    stack[sp++] = 0;
+    while (sp) {
+        const struct zdro_bnode *b = &s->bvh[stack[--sp]];
+        if (!box_hit(b, r, inv, h.t)) continue;
+        if (b->count > 0) {
+            for (int i = b->left; i < b->left + b->count; i++) {
+                const int t = s->bvh_tri[i];
+                float tt, u, v;
+                /* tri_intersect wants tt < tmax: ask with the next float above the best t so that ties reach the index test */
+                if (tri_intersect(s->planes + 12 * (size_t)t, r, best < 0 ? h.t : nextafterf(h.t, 3.0e38f), &tt, &u, &v) &&
+                    (best < 0 || tt < h.t || t < best)) {
+                    h.t = tt; h.u = u; h.v = v; best = t;
+                }
+            }
+        } else if (sp + 2 <= 128) { stack[sp++] = b->left; stack[sp++] = b->left + 1; }
+    }
+    if (best >= 0) { h.inst = s->tri_inst[best]; h.prim = best - s->tri_begin[h.inst]; }
     return h;
 }
 
 static int trace_any(const zdro_scene *s, const ray_t *r) {
-    for (int t = 0; t < s->ntris; t++) {
-        float tt, u, v;
-        if (tri_intersect(s->planes + 12 * (size_t)t, r, r->tmax, &tt, &u, &v)) return 1;
+    if (!s->bvh || g_force_brute) {
+        for (int t = 0; t < s->ntris; t++) {
+            float tt, u, v;
+            if (tri_intersect(s->planes + 12 * (size_t)t, r, r->tmax, &tt, &u, &v)) return 1;
+        }
+        return 0;
+    }
+    const float inv[3] = {1.0f / r->d.x, 1.0f / r->d.y, 1.0f / r->d.z};
+    int stack[128], sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const struct zdro_bnode *b = &s->bvh[stack[--sp]];
+        if (!box_hit(b, r, inv, r->tmax)) continue;
+        if (b->count > 0) {
+            for (int i = b->left; i < b->left + b->count; i++) {
+                float tt, u, v;
+                if (tri_intersect(s->planes + 12 * (size_t)s->bvh_tri[i], r, r->tmax, &tt, &u, &v)) return 1;
+            }
+        } else if (sp + 2 <= 128) { stack[sp++] = b->left; stack[sp++] = b->left + 1; }
     }
     return 0;
 }

@@ -79,6 +79,9 @@ int zdro_path_dump(const zdro_scene *, const zdro_params *, const float *materia
 
 /* Batch ray queries (LuisaCompute Accel.trace_closest / trace_any).
  * rays: n x 8 {o[3], tmin, d[3], tmax}; hits: n x 4 {inst, prim, as-float u, v}, t in tout. */
+/* The oracle searches scenes above 256 triangles through its own binary BVH (same triangle test, same answer as the loop over
+ * every triangle: smallest t, then smallest triangle index); 1 = loop over every triangle instead (tests compare the two). */
+void zdro_debug_force_brute(int on);
 void zdro_trace_closest(const zdro_scene *, const float *rays, int n, int32_t *inst_prim /* n x 2 */,
                         float *bary_t /* n x 3: u, v, t */);
 void zdro_trace_any(const zdro_scene *, const float *rays, int n, int32_t *occluded);

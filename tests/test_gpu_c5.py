@@ -1,6 +1,6 @@
 """-m gpu: BASELINE configs[4] — the 1,004,672-triangle tessellated Cornell box (zdr_amd/procedural.py), BVH accel.
-Forward AND PRB backward against the oracle (which brute-forces the million triangles: a few thousand paths take it
-seconds), path by path and as image / gradient texture; and the gradient bar of BASELINE.json on this scene: AD against
+Forward AND PRB backward against the oracle (which searches the million triangles through its own binary BVH — same
+triangle test, same answers as its loop over every triangle, tests/test_oracle_render.py), path by path and as image / gradient texture; and the gradient bar of BASELINE.json on this scene: AD against
 finite differences of the forward render as a whole-image directional derivative."""
 import numpy as np
 import pytest
@@ -25,25 +25,31 @@ def million():
     return A, scene, oracle.OracleScene.from_arrays(A), oracle.OracleScene.from_arrays(A, variant="fma")
 
 
-def test_rays_against_brute_force(million):
+def test_rays_against_the_oracle(million):
     A, scene, S, Sf = million
-    rays = random_rays(3000, (-2.5, 0.3, -5.3), (2.0, 4.8, -0.8), seed=5)
+    rays = random_rays(200000, (-2.5, 0.3, -5.3), (2.0, 4.8, -0.8), seed=5)
     ip, bt = scene.trace_closest(torch.from_numpy(rays).cuda())
     rip, rbt = S.trace_closest(rays)
     ip, bt = ip.cpu().numpy(), bt.cpu().numpy()
     same = (ip == rip).all(axis=1)
     assert same.mean() > 0.998                                   # a ray through a shared edge may report either neighbour
     hit = same & (rip[:, 0] >= 0)
-    np.testing.assert_allclose(bt[hit, 2], rbt[hit, 2], rtol=2e-5, atol=1e-6)
-    # the other hits: the neighbouring triangle at the same distance
-    np.testing.assert_allclose(bt[~same, 2], rbt[~same, 2], rtol=1e-4, atol=1e-5)
+    # the bounds of tests/test_gpu_trace.py (check_closest): t = (n.p0 - n.o) / (n.d) cancels, so its error is absolute — about an
+    # ulp of the scene's coordinates — on top of the 1-ulp v_rcp_f32: |dt| <= 1e-5 |t| + 5e-6 for 99.98 % of the rays, 50x that for all
+    terr = np.abs(bt[hit, 2] - rbt[hit, 2]) / (1e-5 * np.abs(rbt[hit, 2]) + 5e-6)
+    assert (terr > 1).mean() < 2e-4 and terr.max() < 50, (terr.max(), (terr > 1).mean())
+    # the others: the neighbouring triangle at the same distance — or, for a ray exactly along a shared edge, a hit on one side and
+    # a miss on the other (the bound of test_gpu_trace.check_closest: fewer than 2 in 10,000 rays)
+    both = ~same & (ip[:, 0] >= 0) & (rip[:, 0] >= 0)
+    assert ((ip[:, 0] >= 0) != (rip[:, 0] >= 0)).mean() < 2e-4
+    np.testing.assert_allclose(bt[both, 2], rbt[both, 2], rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("material", ["A", "B"])
 def test_forward_and_backward_match_the_oracle(material, million):
     A, scene, S, Sf = million
     mat = cbox_material_np() if material == "A" else fd_material_np(1024, 0)
-    W, H, spp, seed = 24, 24, 4, 3
+    W, H, spp, seed = 96, 96, 8, 3                                # 73,728 paths (2,304 while the oracle had to loop over the million triangles)
     m = torch.from_numpy(mat).cuda().requires_grad_()
     cot = np.random.default_rng(1).uniform(0.5, 1.5, (H, W, 4)).astype(np.float32)
     img = scene.render(m, res=(W, H), spp=spp, seed=seed)
@@ -60,7 +66,7 @@ def test_forward_and_backward_match_the_oracle(material, million):
     st = deviation_percentiles(tr, rt)
     print(f"[paths] 1M triangles material {material}: {st}")
     if material == "A":
-        assert st["flipped"] <= 6, st                           # of 2304 paths (cbox: 0.02 % - 0.2 %; shared edges add a few)
+        assert st["flipped"] <= 2.6e-3 * n, st                   # round 2's bar (6 of 2,304 paths); measured: 42 of 73,728 — a hit next to a shared edge of the 6 mm triangles reports the neighbour
         assert st["L"][50] <= 2e-6 and st["grad"][50] <= 2e-6 and st["L"][99] <= 1e-3 and st["grad"][99] <= 1e-3, st
     else:
         # glossy bounces over 6 mm triangles: a direction that differs in the fifth digit lands on the neighbouring

@@ -206,3 +206,44 @@ def test_adjoint_follows_the_unclamped_russian_roulette(cbox_oracle):
     fd_mean, fd_se = np.mean(fd), np.std(fd, ddof=1) / np.sqrt(len(fd))
     assert abs(res[oracle.PRB_CORRECT] - fd_mean) < max(4 * fd_se, 0.02 * abs(fd_mean)), (res, fd_mean, fd_se)
     assert abs(res[oracle.PRB_DETACHED] - fd_mean) > 0.2 * abs(fd_mean), (res, fd_mean)
+
+
+def test_the_oracles_search_structure_changes_no_answer():
+    """Scenes above 256 triangles are searched through the oracle's own binary BVH (oracle/zdr_oracle.c, build_bvh): the
+    same plane-form test on fewer triangles.  Closest hits (instance, primitive, barycentrics, t — also on exact ties, which
+    go to the smallest triangle index as in the loop), occlusion queries and a whole path-traced image with its gradient are
+    BIT-IDENTICAL to the loop over every triangle."""
+    from conftest import fd_material_np
+    from gpu_util import terrain_arrays
+    A = terrain_arrays(n=40)                                   # 3,202 triangles, with exactly shared edges (ties)
+    S = oracle.OracleScene.from_arrays(A)
+    rng = np.random.default_rng(3)
+    n = 20000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = rng.uniform((-3, -0.5, -3), (3, 3.5, 3), (n, 3))
+    d = rng.standard_normal((n, 3)); rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True); rays[:, 7] = 1e30
+    # rays aimed exactly at mesh vertices and edge midpoints: the ties
+    V = A.verts[A.tris[:2000].reshape(-1), :3].reshape(-1, 3, 3)
+    targets = np.concatenate([V[:, 0], 0.5 * (V[:, 0] + V[:, 1])])
+    o = np.array([0.3, 3.9, 0.2], np.float32)
+    aimed = np.zeros((targets.shape[0], 8), np.float32); aimed[:, 0:3] = o
+    dd = targets - o; aimed[:, 4:7] = dd / np.linalg.norm(dd, axis=1, keepdims=True); aimed[:, 7] = 1e30
+    rays = np.concatenate([rays, aimed])
+    L = oracle.lib()
+    try:
+        ip, bt = S.trace_closest(rays)
+        rays2 = rays.copy(); rays2[:, 3] = 1e-4; rays2[:, 7] = rng.uniform(0.05, 5.0, rays.shape[0])
+        occ = S.trace_any(rays2)
+        mat = fd_material_np(64, 5)
+        p = oracle.make_params("path", 24, 24, 8, 2, (0.9, (0.5, 3.0, 6.5), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)), mat.shape[:2])
+        img = S.render_forward(p, mat); g = S.render_backward(p, np.ones((24, 24, 4), np.float32), mat)
+        L.zdro_debug_force_brute(1)
+        ip_b, bt_b = S.trace_closest(rays)
+        assert np.array_equal(ip, ip_b) and np.array_equal(bt.view(np.uint32), bt_b.view(np.uint32))
+        assert (ip[:, 0] >= 0).mean() > 0.3
+        assert np.array_equal(occ, S.trace_any(rays2))
+        assert np.array_equal(img.view(np.uint32), S.render_forward(p, mat).view(np.uint32))
+        assert np.array_equal(g, S.render_backward(p, np.ones((24, 24, 4), np.float32), mat))
+        assert img[..., :3].mean() > 0.01
+    finally:
+        L.zdro_debug_force_brute(0)

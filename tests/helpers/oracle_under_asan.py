@@ -24,5 +24,12 @@ p.integrator = oracle.UVGRAD; print("uvgrad", float(np.abs(S.render_forward(p, m
 e = np.zeros((5, 3), np.float32); e[2] = 3; S.set_emissions(e); print("lights", float(S.render_forward(oracle.make_params("path", 8, 8, 4, 1, CBOX_CAMERA, mat.shape[:2]), mat)[..., :3].mean()))
 rays = np.random.default_rng(1).uniform(-1, 1, (100, 8)).astype(np.float32); rays[:, 7] = 1e30
 print(S.trace_closest(rays)[0][:3].tolist(), S.trace_any(rays)[:5].tolist())
+# a scene above 256 triangles: the oracle's own BVH (build, closest / any hit with NaN and axis-parallel rays, a render)
+from gpu_util import terrain_arrays
+T = oracle.OracleScene.from_arrays(terrain_arrays(n=20), variant="asan")
+rays = np.random.default_rng(2).uniform(-3, 3, (400, 8)).astype(np.float32); rays[:, 3] = 0; rays[:, 7] = 1e30
+rays[0, 4:7] = (0, -1, 0); rays[1, 4:7] = (1, 0, 0); rays[2, 4:7] = np.nan; rays[3, 0:3] = np.nan
+print("bvh", int((T.trace_closest(rays)[0][:, 0] >= 0).sum()), int(T.trace_any(rays).sum()),
+      float(T.render_forward(oracle.make_params("path", 12, 12, 4, 1, (0.9, (0.5, 3.0, 6.5), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)), mat.shape[:2]), mat)[..., :3].mean()))
 print("sampler", oracle.sampler_dump(oracle.SAMPLER_CMJ, 3, 4, 5, 16, 7)[:4])
 print("ok")

@@ -95,7 +95,7 @@ class Scene:
     def add_envmap(self, image, compensate_mis=True):
         """Adds a lat-long environment light (render.py:150-156, envmap.py:116-203).  ``image`` is an
         (H, W, 3|4) float array / tensor (2:1 or 1:1) or the path of an OpenEXR file (the reference reads it
-        through imageio; here zdr_amd/exr.py: scan-line files, NONE / ZIPS / ZIP compression) or of a ``.npy``
+        through imageio; here zdr_amd/exr.py: scan-line files, NONE / RLE / ZIPS / ZIP / PIZ compression) or of a ``.npy``
         file.  ``None`` removes it."""
         from . import envmap as E
         if image is None:

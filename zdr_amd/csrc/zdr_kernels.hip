@@ -14,6 +14,9 @@
 #include "zdr.h"
 
 #define WAVE 64
+#ifndef ZDR_SWEEP_PINGPONG
+#define ZDR_SWEEP_PINGPONG 1   // the backward sweep loop unrolled by two with swapped record registers (0: one step per iteration and a copy)
+#endif
 // __launch_bounds__ second argument = minimum waves per SIMD (caps the VGPR budget at 512 / n).
 // Measured on cbox 512^2 spp 256 (profiles/r1_ab_flags.txt): 3 (<= 168 VGPRs, no spills) is best for both.
 
@@ -399,26 +402,41 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             st_fin += (unsigned long long)__popcll(__ballot(sw_k >= 0));
 #endif
             int sweep_cap = (R.debug_no_scatter == 4) ? 2 : ((R.debug_no_scatter == 5) ? 1 : 64);   // timing-only ablations 4 / 5: the sweep loop cut after 2 / 1 iterations
-            while (__ballot(sw_k >= 0) != 0ull && sweep_cap-- > 0) {
+            // One step: the record of the NEXT step is fetched into `fill` while `use` is consumed.  The loop body below runs two
+            // steps with the roles of the two register sets swapped, so that no record is ever copied from one set to the other
+            // (20 v_mov per step otherwise; the loop runs 5.45 times per trip, profiles/r3_bwd_sweep_ablation.txt).
+            auto sweep_step = [&](const PackedVertex &use, PackedVertex &fill) {
                 const bool swp = sw_k >= 0;
 #ifdef ZDR_BWD_STATS
                 st_iters++; st_steps += (unsigned long long)__popcll(__ballot(swp));
 #endif
-                PackedVertex nxt = cur;
                 if (swp && sw_k >= 1) {
                     const int k = sw_k - 1;
                     if (k < lds_vertices) {
                         const float4 *r = lds_rec + (k * 4) * WAVE + lane;
-                        nxt.a = r[0]; nxt.b = r[WAVE]; nxt.c = r[2 * WAVE]; nxt.d = r[3 * WAVE];
-                        nxt.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[k * WAVE + lane]);
-                    } else nxt = deep[k];
+                        fill.a = r[0]; fill.b = r[WAVE]; fill.c = r[2 * WAVE]; fill.d = r[3 * WAVE];
+                        fill.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[k * WAVE + lane]);
+                    } else fill = deep[k];
                 }
                 float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 f2 guv; guv.x = 0.0f; guv.y = 0.0f;
-                if (swp) { g = sweep_vertex(cur, sw, guv); sw_k--; }
+                if (swp) { g = sweep_vertex(use, sw, guv); sw_k--; }
                 scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
+            };
+#if ZDR_SWEEP_PINGPONG
+            PackedVertex nxt = plast;
+            while (__ballot(sw_k >= 0) != 0ull && sweep_cap-- > 0) {
+                sweep_step(cur, nxt);
+                if (__ballot(sw_k >= 0) == 0ull || sweep_cap-- <= 0) break;
+                sweep_step(nxt, cur);
+            }
+#else
+            while (__ballot(sw_k >= 0) != 0ull && sweep_cap-- > 0) {
+                PackedVertex nxt = cur;
+                sweep_step(cur, nxt);
                 cur = nxt;
             }
+#endif
         }
 #pragma unroll
         for (int b = 0; b < 2; b++)                         // an item whose samples are all generated and whose paths have ended frees its bank

@@ -15,7 +15,7 @@
 
 #define WAVE 64
 #ifndef ZDR_SWEEP_PINGPONG
-#define ZDR_SWEEP_PINGPONG 1   // the backward sweep loop unrolled by two with swapped record registers (0: one step per iteration and a copy)
+#define ZDR_SWEEP_PINGPONG 0   // 1: the backward sweep loop unrolled by two with swapped record registers — measured SLOWER (14.33 vs 14.14 ms: 153 instead of 146 VGPRs and twice the loop body outweigh the 20 v_mov saved per step; profiles/r3_bwd_sweep_ablation.txt)
 #endif
 // __launch_bounds__ second argument = minimum waves per SIMD (caps the VGPR budget at 512 / n).
 // Measured on cbox 512^2 spp 256 (profiles/r1_ab_flags.txt): 3 (<= 168 VGPRs, no spills) is best for both.
@@ -402,9 +402,8 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
             st_fin += (unsigned long long)__popcll(__ballot(sw_k >= 0));
 #endif
             int sweep_cap = (R.debug_no_scatter == 4) ? 2 : ((R.debug_no_scatter == 5) ? 1 : 64);   // timing-only ablations 4 / 5: the sweep loop cut after 2 / 1 iterations
-            // One step: the record of the NEXT step is fetched into `fill` while `use` is consumed.  The loop body below runs two
-            // steps with the roles of the two register sets swapped, so that no record is ever copied from one set to the other
-            // (20 v_mov per step otherwise; the loop runs 5.45 times per trip, profiles/r3_bwd_sweep_ablation.txt).
+            // One step: the record of the NEXT step is fetched into `fill` while `use` is consumed (the loop runs 5.45 times per
+            // trip at 18 % of the lanes, profiles/r3_bwd_sweep_ablation.txt).
             auto sweep_step = [&](const PackedVertex &use, PackedVertex &fill) {
                 const bool swp = sw_k >= 0;
 #ifdef ZDR_BWD_STATS

@@ -7,7 +7,7 @@ build by.  The HIP build perturbs MORE operations than that ruler does — FMA c
 v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 / device sin, cos at 1-2 ulp each — so its distance from the IEEE oracle is a multiple
 of the ruler.  This tool measures that multiple: for many seeds it renders forward + backward on the GPU and with both CPU
 builds, sets aside the paths that measurably took another branch (tests/gpu_util.Flips, all three builds), and prints the
-ratio HIP-vs-IEEE / FMA-vs-IEEE of every robust statistic the parity assertions use.  tests/gpu_util.FLOOR_FACTORS quotes
+ratio HIP-vs-IEEE / FMA-vs-IEEE of every robust statistic the parity assertions use.  tests/gpu_util.FLOOR_FACTOR quotes
 the result (profiles/r3_glossy_floor_ratio.txt).
 """
 import argparse

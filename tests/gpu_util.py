@@ -27,7 +27,7 @@ def image_diff_stats(got, ref):
 
 
 # Glossy inputs: each robust statistic may reach FLOOR_FACTOR x what the oracle's own FMA and IEEE builds differ by.  MEASURED
-# (tools/glossy_floor.py, profiles/r3_glossy_floor_ratio.txt: 16 seeds x 4 scenes, flipped paths of all builds set aside): on renders
+# (tests/measure/glossy_floor.py, profiles/r3_glossy_floor_ratio.txt: 16 seeds x 4 scenes, flipped paths of all builds set aside): on renders
 # of 64^2 x 16 paths and more the ratio HIP-vs-IEEE / FMA-vs-IEEE has median 1.10 - 1.24, 90th percentile 1.12 - 1.54, maximum 1.65
 # — the HIP build perturbs more operations than FMA contraction alone (v_rcp / v_rsq / v_sqrt, device sin and cos at 1 - 2 ulp).
 # On renders of a few thousand paths the ratio of two such small numbers is noise (maximum 5.7): those sizes are compared path by
@@ -155,77 +155,6 @@ def assert_grad_parity(got, ref, what, floor=None, frac_bad=2e-3, rel_l1=2e-4, s
     return st
 
 
-def terrain_arrays(n=64, seed=0, light=True):
-    """Procedural BVH-stress scene: an n x n displaced height-field (2 n^2 triangles, smooth normals,
-    UV atlas = the unit square) lit by a quad light above it; instance 0 textured, instance 1 light."""
-    rng = np.random.default_rng(seed)
-    g = np.linspace(-3.0, 3.0, n + 1, dtype=np.float32)
-    X, Z = np.meshgrid(g, g, indexing="xy")
-    Y = (0.35 * np.sin(1.7 * X) * np.cos(1.3 * Z) + 0.05 * rng.standard_normal(X.shape)).astype(np.float32)
-    P = np.stack([X, Y, Z], -1).reshape(-1, 3)
-    U = np.stack([(X + 3) / 6, (Z + 3) / 6], -1).reshape(-1, 2).astype(np.float32)
-    idx = lambda i, j: i * (n + 1) + j
-    tris = []
-    for i in range(n):
-        for j in range(n):
-            a, b, c, d = idx(i, j), idx(i, j + 1), idx(i + 1, j + 1), idx(i + 1, j)
-            tris += [(a, c, b), (a, d, c)]          # wound so that normals point +y
-    tris = np.asarray(tris, np.int32)
-    verts = np.zeros((P.shape[0], 8), np.float32)
-    verts[:, 0:3] = P; verts[:, 3:5] = U; verts[:, 5:8] = np.nan
-    geometry.recompute_normal(verts, tris)
-    lv = np.array([[-1, 4, -1, 0, 0, 0, -1, 0], [1, 4, -1, 0, 0, 0, -1, 0], [1, 4, 1, 0, 0, 0, -1, 0], [-1, 4, 1, 0, 0, 0, -1, 0]], np.float32)
-    lt = np.array([[0, 1, 2], [0, 2, 3]], np.int32) + verts.shape[0]
-    V = np.concatenate([verts, lv]); T = np.concatenate([tris, lt])
-    em = np.array([[0, 0, 0], [30, 30, 30]], np.float32) if light else np.zeros((2, 3), np.float32)
-    return geometry.from_arrays(V, T, [0, tris.shape[0], T.shape[0]], None, em)
+from zdr_amd.scenes import multi_light_arrays, panel_mesh, random_rays, terrain_arrays, terrain_camera  # noqa: E402,F401  (scene builders live in the product package; re-exported)
 
-
-TERRAIN_CAMERA = Camera(fov=0.9, origin=float3(0.5, 3.0, 6.5), target=float3(0.0, 0.0, 0.0), up=float3(0.0, 1.0, 0.0))
-
-
-def random_rays(n, lo, hi, seed=0, tmax=1e30):
-    rng = np.random.default_rng(seed)
-    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
-    d = rng.standard_normal((n, 3)).astype(np.float32)
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    r = np.zeros((n, 8), np.float32)
-    r[:, 0:3] = o; r[:, 3] = 0.0; r[:, 4:7] = d; r[:, 7] = tmax
-    return r
-
-
-def panel_mesh(nx, ny):
-    """A 2 x 2 panel in the xz plane facing +y (like quad.obj), cut into nx x ny cells of two triangles each:
-    2 nx ny triangles, per-vertex normal (0, 1, 0), uv = the unit square."""
-    gx = np.linspace(-1.0, 1.0, nx + 1, dtype=np.float32); gz = np.linspace(-1.0, 1.0, ny + 1, dtype=np.float32)
-    verts = np.zeros(((nx + 1) * (ny + 1), 8), np.float32)
-    k = 0
-    for j in range(ny + 1):
-        for i in range(nx + 1):
-            verts[k] = (gx[i], 0.0, gz[j], (gx[i] + 1) / 2, (gz[j] + 1) / 2, 0.0, 1.0, 0.0); k += 1
-    tris = []
-    for j in range(ny):
-        for i in range(nx):
-            a, b, c, d = j * (nx + 1) + i, j * (nx + 1) + i + 1, (j + 1) * (nx + 1) + i + 1, (j + 1) * (nx + 1) + i
-            tris += [(a, c, b), (a, d, c)]          # wound so that cross(p1 - p0, p2 - p0) points +y
-    return verts, np.asarray(tris, np.int32)
-
-
-def multi_light_arrays(emissions=((0, 0, 0), (20, 20, 20), (6, 2, 1), (0, 0, 0), (1, 3, 8))):
-    """Light-stage style scene (test_lightstage.py:24-62): the Cornell box (instance 0, textured) with FOUR more
-    instances of DIFFERENT triangle counts — the ceiling light (2 triangles), a warm panel on the left wall (8),
-    a blocker slab in mid-air (2, never emits: the light list must skip it) and a cool panel on the back wall (6),
-    each with its own transform.  `emissions` has one rgb per instance."""
-    from zdr_amd.mathtypes import as_row_major_4x4
-    base = geometry.assemble(cbox_models())
-    V = [base.verts]; T = [base.tris]; begin = list(base.inst_tri_begin); X = [base.inst_xform[0], base.inst_xform[1]]
-    def add(verts, tris, xform):
-        nv = sum(v.shape[0] for v in V)
-        V.append(verts); T.append(tris + nv); begin.append(begin[-1] + tris.shape[0]); X.append(np.asarray(xform, np.float32).reshape(16))
-    # left wall x = -3.0: panel normal +y -> +x (rotate about z by -90 degrees), scaled 0.5 x 1.0
-    add(*panel_mesh(2, 2), [[0, 1, 0, -2.9], [-1.0, 0, 0, 2.5], [0, 0, 0.5, -3.0], [0, 0, 0, 1]])
-    # blocker: a slab facing down, hanging under the ceiling light
-    add(*panel_mesh(1, 1), [[0.6, 0, 0, -0.2], [0, -1, 0, 4.2], [0, 0, -0.6, -3.0], [0, 0, 0, 1]])
-    # back wall z = -5.8: panel normal +y -> +z, 3 x 1 cells
-    add(*panel_mesh(3, 1), [[0.9, 0, 0, 0.4], [0, 0, -0.4, 1.6], [0, 1, 0, -5.7], [0, 0, 0, 1]])
-    return geometry.from_arrays(np.concatenate(V), np.concatenate(T), begin, np.stack(X), np.asarray(emissions, np.float32))
+TERRAIN_CAMERA = terrain_camera()

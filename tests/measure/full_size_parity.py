@@ -2,7 +2,7 @@
 """BASELINE configs[2] at FULL size (cbox, path, 512x512, spp 256): HIP forward image and PRB gradient against the
 CPU oracle on the same seed, with the oracle's own IEEE-vs-FMA difference beside them as the fp32 floor."""
 import argparse, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import oracle

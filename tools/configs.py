@@ -4,8 +4,8 @@ import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from conftest import cbox_material_np, cbox_models
-from gpu_util import make_scene
+from zdr_amd.scenes import cbox_material_np, cbox_models
+from zdr_amd.scenes import make_scene
 from zdr_amd import procedural
 
 def timed(fn, iters=3):

@@ -2,8 +2,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from conftest import cbox_material_np
-from gpu_util import make_scene
+from zdr_amd.scenes import cbox_material_np
+from zdr_amd.scenes import make_scene
 m = torch.from_numpy(cbox_material_np()).cuda()
 for integ, depths in (("collocated", [1]), ("direct", [1]), ("path", [1, 2, 3, 4, 16])):
     scene = make_scene(integ)

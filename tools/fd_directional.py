@@ -7,8 +7,8 @@ import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from conftest import fd_material_np
-from gpu_util import make_scene
+from zdr_amd.scenes import fd_material_np
+from zdr_amd.scenes import make_scene
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=256)
@@ -20,17 +20,17 @@ ap.add_argument("--eps", type=float, default=0.01)
 ap.add_argument("--scene", default="cbox", choices=["cbox", "tess1m", "env", "lights3"],
                 help="tess1m: the 1,004,672-triangle tessellated cbox (BASELINE configs[4], BVH kernels); env: cbox + a sun-and-sky "
                      "environment map (the adjoint of the environment's light sampling and MIS); lights3: three emitters of different "
-                     "sizes and colours plus a blocker (tests/gpu_util.py, multi_light_arrays)")
+                     "sizes and colours plus a blocker (zdr_amd/scenes.py, multi_light_arrays)")
 ap.add_argument("--integrator", default="path", choices=["path", "direct"])
 ap.add_argument("--only", default="", help="comma list of diffuse,roughness,all")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fd_directional.json"))
 a = ap.parse_args()
 if a.scene == "tess1m":
-    from conftest import cbox_models
+    from zdr_amd.scenes import cbox_models
     from zdr_amd import procedural
     scene = make_scene(a.integrator, arrays=procedural.tessellated_cbox(cbox_models(), n=183))
 elif a.scene == "lights3":
-    from gpu_util import multi_light_arrays
+    from zdr_amd.scenes import multi_light_arrays
     scene = make_scene(a.integrator, arrays=multi_light_arrays())
 else:
     scene = make_scene(a.integrator)

@@ -16,8 +16,8 @@ import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from conftest import fd_material_np
-from gpu_util import make_scene
+from zdr_amd.scenes import fd_material_np
+from zdr_amd.scenes import make_scene
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--channel", default="any", choices=["any", "diffuse", "roughness"])

@@ -12,5 +12,5 @@ timeout -k 10 300 python tools/configs.py > $out/configs.txt 2>&1; cp gpurun_out
 bash tools/rehearse_dist.sh > $out/two_rank_gloo_rehearsal.txt 2>&1
 timeout -k 10 200 python tools/trace_bench.py > $out/trace_bench_1m.txt 2>&1
 timeout -k 10 300 python tools/hotspot_bench.py --out $out/hotspot.json > $out/hotspot.txt 2>&1
-timeout -k 10 600 python tools/full_size_parity.py > $out/full_size_parity.txt 2>&1; cp gpurun_out/full_size_parity.json $out/ 2>/dev/null
+timeout -k 10 600 python tests/measure/full_size_parity.py > $out/full_size_parity.txt 2>&1; cp gpurun_out/full_size_parity.json $out/ 2>/dev/null
 ls $out

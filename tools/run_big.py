@@ -4,8 +4,8 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from conftest import fd_material_np
-from gpu_util import TERRAIN_CAMERA, make_scene, terrain_arrays
+from zdr_amd.scenes import fd_material_np
+from zdr_amd.scenes import make_scene, terrain_arrays, terrain_camera
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="tess", choices=["tess", "terrain"])
@@ -14,13 +14,13 @@ ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--iters", type=int, default=2)
 a = ap.parse_args()
-from conftest import cbox_models, cbox_material_np
+from zdr_amd.scenes import cbox_models, cbox_material_np
 from zdr_amd import procedural
 t0 = time.time()
 A = procedural.tessellated_cbox(cbox_models(), n=a.n or 183) if a.scene == "tess" else terrain_arrays(n=a.n or 707)
 t1 = time.time()
 scene = make_scene("path", arrays=A)
-if a.scene == "terrain": scene.camera = TERRAIN_CAMERA
+if a.scene == "terrain": scene.camera = terrain_camera()
 t2 = time.time()
 print("scene:", scene.info(), f"gen {t1-t0:.1f}s build {t2-t1:.1f}s")
 m = torch.from_numpy(cbox_material_np() if a.scene == "tess" else fd_material_np(1024, 0)).cuda()

@@ -5,8 +5,8 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from conftest import cbox_material_np, fd_material_np
-from gpu_util import make_scene
+from zdr_amd.scenes import cbox_material_np, fd_material_np
+from zdr_amd.scenes import make_scene
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--which", default="fwd", choices=["fwd", "bwd", "both"])

@@ -5,8 +5,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from conftest import cbox_models, CBOX_CAMERA
-from gpu_util import make_scene
+from zdr_amd.scenes import cbox_models, CBOX_CAMERA
+from zdr_amd.scenes import make_scene
 from zdr_amd import procedural
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 183

@@ -49,6 +49,64 @@ __global__ __launch_bounds__(64) void k(const float4 *__restrict__ rec, uint32_t
     out[blockIdx.x * 64 + lane] = acc;
 }
 
+// Round 3: (a) what does a per-lane 4 x dwordx4 fetch cost when only some lanes are ACTIVE (a BVH walk runs at a third of its lanes:
+// is the vector-memory path charged per instruction or per active lane?), and (b) what would the same record cost from LDS
+// (a per-wave cache of the top levels of the tree: 21 nodes = 1,344 B, divergent 64-byte-aligned ds_read_b128 x 4).
+template <int STRIDE>
+__global__ __launch_bounds__(64) void k_partial(const float4 *__restrict__ rec, uint32_t mask, int visits, float *out) {
+    const int lane = threadIdx.x;
+    uint32_t idx = hash32(blockIdx.x * 64u + lane + 1u) & mask;
+    float acc = 0.0f;
+    const bool active = (lane % STRIDE) == 0;
+    for (int v = 0; v < visits; v++) {
+        float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0;
+        if (active) { const float4 *p = rec + 4 * (size_t)idx; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; }
+        acc += n0.x + n1.y + n2.z;
+        idx = hash32(idx + 0x9e3779b9u * (uint32_t)(v + 1) + __float_as_uint(n3.w)) & mask;
+    }
+    out[blockIdx.x * 64 + lane] = acc;
+}
+template <int NODES>
+__global__ __launch_bounds__(64) void k_lds(const float4 *__restrict__ rec, int visits, float *out) {
+    __shared__ float4 top[4 * NODES];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 4 * NODES; i += 64) top[i] = rec[i];
+    __syncthreads();
+    uint32_t idx = hash32(blockIdx.x * 64u + lane + 1u) % NODES;
+    float acc = 0.0f;
+    for (int v = 0; v < visits; v++) {
+        const float4 *p = top + 4 * idx;
+        float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
+        acc += n0.x + n1.y + n2.z;
+        idx = hash32(idx + 0x9e3779b9u * (uint32_t)(v + 1) + __float_as_uint(n3.w)) % NODES;
+    }
+    out[blockIdx.x * 64 + lane] = acc;
+}
+template <int STRIDE> static void run_partial(const float4 *rec, size_t nrec, float *out, int waves_per_cu) {
+    const int visits = 400, blocks = 256 * waves_per_cu;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k_partial<STRIDE><<<blocks, 64>>>(rec, (uint32_t)(nrec - 1), 20, out);
+    hipEventRecord(e0);
+    k_partial<STRIDE><<<blocks, 64>>>(rec, (uint32_t)(nrec - 1), visits, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double wave_visits = (double)blocks * visits;
+    printf("per-lane 4 x dwordx4, %2d of 64 lanes active      %8zu records (%5.1f MiB) %2d waves/CU: %6.1f cycles of the CU per wave-visit (%5.2f per active lane)\n", 64 / STRIDE, nrec,
+           nrec * 64 / 1048576.0, waves_per_cu, ms * 1e-3 * 2.4e9 / (wave_visits / 256), ms * 1e-3 * 2.4e9 / (wave_visits / 256) / (64 / STRIDE));
+}
+template <int NODES> static void run_lds(const float4 *rec, float *out, int waves_per_cu) {
+    const int visits = 400, blocks = 256 * waves_per_cu;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k_lds<NODES><<<blocks, 64>>>(rec, 20, out);
+    hipEventRecord(e0);
+    k_lds<NODES><<<blocks, 64>>>(rec, visits, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double wave_visits = (double)blocks * visits;
+    printf("from LDS, 4 x ds_read_b128 per lane, %3d records (%5d B per wave)        %2d waves/CU: %6.1f cycles of the CU per wave-visit\n", NODES, NODES * 64, waves_per_cu,
+           ms * 1e-3 * 2.4e9 / (wave_visits / 256));
+}
+
 template <int MODE> static void run(const char *name, const float4 *rec, size_t nrec, float *out, int waves_per_cu) {
     const int visits = 400, blocks = 256 * waves_per_cu;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -80,7 +138,9 @@ int main() {
             run<4>("per-lane 3 x dwordx4", rec, nrec, out, w);
             run<5>("per-lane 4 x dwordx2", rec, nrec, out, w);
             run<6>("per-lane 4 x dword", rec, nrec, out, w);
+            run_partial<1>(rec, nrec, out, w); run_partial<2>(rec, nrec, out, w); run_partial<4>(rec, nrec, out, w); run_partial<8>(rec, nrec, out, w);
         }
+        if (nrec == ((size_t)1 << 14)) { run_lds<5>(rec, out, 20); run_lds<21>(rec, out, 20); run_lds<85>(rec, out, 16); }
         hipFree(rec); hipFree(out);
     }
     return 0;

@@ -156,6 +156,7 @@ ZD void brute_resolve(const DScene &S, Hit &h, int prim, f3 o, f3 d) {
 
 struct BruteAccel {
     static constexpr bool kNeedsLds = false;
+    ZD static void prepare(const DScene &, int *) {}
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES, kMinWavesFwdEnv = ZDR_MIN_WAVES_ENV;
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD;
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES;    // scratch records thrash L2 on cbox (1 instead of 2: 16.7 -> 19.0 ms)
@@ -251,6 +252,17 @@ struct BvhAccel {
         int sp, id, cnt, budget;
     };
     ZD static int root_count(const DScene &S) { return (S.nnodes == 0) ? S.ntris : 0; }
+    // Called once by the whole wave before its first walk: the top S.lds_top nodes of the tree go to LDS behind the stack.
+    ZD static float4 *top_nodes(const DScene &S, int *stack) { return (float4 *)(stack + S.lds_stack * 64); }
+    ZD static void prepare(const DScene &S, int *stack) {
+#ifndef ZDR_BVH_TOP_CACHE
+        return;
+#endif
+        float4 *top = top_nodes(S, stack);
+        for (int i = threadIdx.x & 63; i < 4 * S.lds_top; i += 64) top[i] = S.nodes[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it impossible for a wave to
     // spin forever whatever the node data or the ray (NaNs) look like.
     ZD static int walk_budget(const DScene &S) { return (S.debug_bvh_budget > 0) ? S.debug_bvh_budget : 2 * (S.nnodes + S.ntris) + 8; }
@@ -270,10 +282,17 @@ struct BvhAccel {
     // entries on a 1 M triangle tree, 11 KiB of LDS per wave) is a worst case that real rays almost never approach,
     // and LDS is what limits the waves per CU of the BVH kernels.
     struct Fetched { float4 n0, n1, n2, n3, n4, n5; bool dead; };
-    ZD static Fetched fetch(const DScene &S, Walker &w) {
+    ZD static Fetched fetch(const DScene &S, int *stack, Walker &w) {
         Fetched f;
         f.dead = (--w.budget < 0);
         f.n0 = f.n1 = f.n2 = f.n3 = f.n4 = f.n5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#ifdef ZDR_BVH_TOP_CACHE
+        if ((w.cnt == 0) & (w.id < S.lds_top)) {              // the top of the tree: from this wave's LDS copy (experiment, scene.h)
+            const float4 *q = top_nodes(S, stack) + 4 * w.id;
+            if (!f.dead) { f.n0 = q[0]; f.n1 = q[1]; f.n2 = q[2]; f.n3 = q[3]; }
+            return f;
+        }
+#endif
         const float4 *p = (w.cnt == 0) ? S.nodes + 4 * (size_t)w.id : S.isect + 3 * (size_t)w.id;   // isect is padded by one record
         if (!f.dead) { f.n0 = p[0]; f.n1 = p[1]; f.n2 = p[2]; f.n3 = p[3]; }
         if (!f.dead && w.cnt > 1) { f.n4 = p[4]; f.n5 = p[5]; }
@@ -349,7 +368,7 @@ struct BvhAccel {
         return false;
     }
     ZD static bool step(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const bool anyhit) {
-        const Fetched f = fetch(S, w);
+        const Fetched f = fetch(S, stack, w);
         return consume(S, stack, LN, deep, w, f, anyhit);
     }
     // One loop walks up to two rays per lane back to back: first (HAS_A) an any-hit ray — the shadow segment of a

@@ -14,6 +14,19 @@
 #ifndef ZDR_BVH_LDS_STACK_BWD
 #define ZDR_BVH_LDS_STACK_BWD 6
 #endif
+// The top of the tree in LDS (a per-wave copy of nodes 0 .. K-1 behind the stack; the builder numbers the top of the tree breadth-first):
+// a divergent 64-byte fetch costs the vector-memory path ~3 cycles per ACTIVE lane from L2 against 20-26 cycles per WAVE from LDS
+// (tools/micro/gather_rate.hip, profiles/r3_gather_rate.txt) — and yet it measured SLOWER on the 1 M-triangle scene (K = 5: equal, 21: +5 %,
+// 64: +20 %; profiles/r3_bvh_lds_top.txt): the top nodes are the ones every wave finds in L1 anyway, the extra branch in the fetch and the
+// LDS taken from the occupancy cost more.  Compiled out unless ZDR_BVH_TOP_CACHE is defined (then ZDR_BVH_LDS_TOP / _BWD nodes, env ZDR_BVH_LDS_TOP).
+#ifdef ZDR_BVH_TOP_CACHE
+#ifndef ZDR_BVH_LDS_TOP
+#define ZDR_BVH_LDS_TOP 21
+#endif
+#ifndef ZDR_BVH_LDS_TOP_BWD
+#define ZDR_BVH_LDS_TOP_BWD 5
+#endif
+#endif
 
 // Per-slot records, 16-byte aligned so a record is fetched with dwordx4 loads:
 //   isect[3*slot + {0,1,2}] = {n, n.p0} {nu, du} {nv, dv}              (48 B, plane-form triangle test)
@@ -47,6 +60,7 @@ struct DScene {
     int32_t env_count, env_h, env_w, map_w, map_h;
     int32_t stack_entries;          // per-lane traversal stack entries this tree needs
     int32_t lds_stack;              // how many of them this launch keeps in LDS (dynamic LDS: lds_stack x 64 ints per wave), set by the launcher
+    int32_t lds_top;                // nodes [0, lds_top) — the top of the tree, numbered breadth-first by the builder — are copied into each wave's LDS behind its stack (accel.h), set by the launcher
     // Device error word (sticky until the host reads it: zdr_scene_check, zdr_render_stats, ZDR_CHECK=1).  A watchdog
     // that ends work early ORs its bit in, so an incomplete image or gradient can never pass as a good one.
     unsigned int *error_word;

@@ -51,6 +51,9 @@ static void normal_matrix(const float *m, float *n) {      // inverse(transpose(
 #define ZDR_BVH_LEAF 2   // 1 M triangles, path fwd / bwd ms at 1024^2 spp 32: leaf 1: 46 / 61, 2: 42 / 56, 3: 43 / 58, 4: 48 / 64, 6: 54 / 72 (a triangle costs three per-lane loads, a node four)
 #endif
 static_assert(ZDR_BVH_LEAF >= 1 && ZDR_BVH_LEAF <= 6, "the child word holds the leaf size in 3 bits, 7 = unused");
+#ifndef ZDR_BVH_BFS_NODES
+#define ZDR_BVH_BFS_NODES 341   // root + four levels of a full BVH4: numbered breadth-first, so that "node id < K" is the top of the tree for any K up to here
+#endif
 struct BNode { float lo[3], hi[3]; int left, right, first, count; };
 struct Prim { float lo[3], hi[3], c[3]; int tri; };
 
@@ -299,12 +302,17 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
     } collapse(bb.nodes);
     int ninner = 0, worst_stack = 0;
     if (bb.nodes[0].count == 0) {
+        // Node numbering: the top of the tree breadth-first (nodes 0 .. ZDR_BVH_BFS_NODES - 1 are the root, its children, their children ...:
+        // the kernels keep the first few in LDS, accel.h), everything below depth-first (a subtree stays together in memory).
         struct Item { int bnode, id4, stack; };
         std::vector<Item> todo; todo.push_back({0, 0, 0});
+        size_t head = 0;                                        // todo[head ..): pending; taken from the front while numbering breadth-first
         ninner = 1;
         nodes.assign(4, make_float4(0, 0, 0, 0));
-        while (!todo.empty()) {
-            Item it = todo.back(); todo.pop_back();
+        while (head < todo.size()) {
+            Item it;
+            if (ninner < ZDR_BVH_BFS_NODES) it = todo[head++];
+            else { it = todo.back(); todo.pop_back(); }
             int kids[4], nk = 0;
             collapse.children(it.bnode, kids, nk);
             float lo[3][4], hi[3][4]; int child[4], cnt[4];

@@ -181,6 +181,7 @@ __global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) v
     __shared__ int lds_origin[4];
     __shared__ float lds_sum[2 * 3 * WAVE];
     const int lane = threadIdx.x;
+    A::prepare(S, lds);
     Counters cnt;
 #pragma unroll
     for (int i = 0; i < 8; i++) cnt.c[i] = 0;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
     if (R.height < 0) io.cells[0] = lds_pad[threadIdx.x ^ 1];
 #endif
     const int lane = threadIdx.x;
+    A::prepare(S, lds);
     const int lds_vertices = (R.rr_depth < LV) ? max(R.rr_depth, 0) : LV;   // LDS records carry no RR fields
     Counters cnt;
     ItemBanks ib; ib.logical[0] = ib.logical[1] = -1; ib.inflight[0] = ib.inflight[1] = 0;
@@ -463,6 +465,7 @@ template <int INTEG, int SK, class A, bool BWD, bool STATS, bool ENV>
 __global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV ? 3 : ZDR_MIN_WAVES_DIRECT) : 1) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 1];
+    A::prepare(S, lds);
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     Counters cnt;
@@ -534,6 +537,7 @@ __global__ void k_cells_to_grad(const float4 *__restrict__ cells, float4 *__rest
 template <int SK, class A>
 __global__ __launch_bounds__(WAVE) void k_uvgrad(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];
+    A::prepare(S, lds);
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -580,7 +584,13 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
 // dynamic LDS of a wave that traverses the BVH: the first entries of the per-lane stacks (accel.h).  Sets S.lds_stack.
 static size_t bvh_dyn_lds(DScene &S, bool backward) {
     S.lds_stack = std::min<int>(S.stack_entries, backward ? ZDR_BVH_LDS_STACK_BWD : ZDR_BVH_LDS_STACK);
-    return (size_t)S.lds_stack * WAVE * sizeof(int);
+    int top = 0;
+#ifdef ZDR_BVH_TOP_CACHE                                                            // experiment (scene.h): measured slower, compiled out by default
+    top = backward ? ZDR_BVH_LDS_TOP_BWD : ZDR_BVH_LDS_TOP;
+    if (const char *e = getenv("ZDR_BVH_LDS_TOP")) top = std::max(0, atoi(e));      // measurement knob (both passes)
+#endif
+    S.lds_top = std::min<int>(S.nnodes, std::min(top, 256));
+    return (size_t)S.lds_stack * WAVE * sizeof(int) + (size_t)S.lds_top * 64;       // the stack (a multiple of 256 B), then the top nodes
 }
 // Persistent grid of the path kernels: as many single-wave workgroups as the chip holds at once (never more
 // than there are items).  A workgroup that is not resident at first simply starts later and draws what is left.
@@ -673,6 +683,7 @@ int zdr_launch_render(const DScene &S_in, const RenderCfg &R, const SamplerCfg &
 template <class A, bool ANY>
 __global__ __launch_bounds__(WAVE) void k_trace(DScene S, const float4 *rays, uint32_t n, int32_t *out_i, float *out_f) {
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
+    A::prepare(S, lds);
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     bool valid = i < n;
     float4 a = valid ? rays[2 * (size_t)i] : make_float4(0, 0, 0, 0), b = valid ? rays[2 * (size_t)i + 1] : make_float4(0, 0, 1, 0);
@@ -719,6 +730,7 @@ int zdr_launch_trace(const DScene &S_in, int accel_is_bvh, int any, const float 
 template <int SK, class A, bool ENV>
 __global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, SamplerCfg C, KernelIO io, const int32_t *queries, uint32_t n, int maxv, float *out) {
     extern __shared__ int lds[];
+    A::prepare(S, lds);                                     // by the whole wave, before any lane leaves
     const uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     if (i >= n) return;                                     // no wave-level operation below: lanes are independent
     const int stride = 8 + 24 * maxv;

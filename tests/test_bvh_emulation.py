@@ -189,3 +189,28 @@ def test_tiny_scene_is_a_single_leaf():
     assert nodes.shape[0] == 0
     slot, t, _ = traverse(nodes, isect, np.array([0.2, 1, 0.2], np.float32), np.array([0, -1, 0], np.float32), np.float32(0), np.float32(1e30), False)
     assert slot == 0 and abs(t - 1) < 1e-6
+
+
+def test_the_top_of_the_tree_is_numbered_breadth_first():
+    """zdr_api.cpp numbers the first ZDR_BVH_BFS_NODES (341) nodes breadth-first — root, its children, their children … — and
+    everything below depth-first: 'node id < K' is the top of the tree for any K up to there (what a kernel would keep in
+    LDS, accel.h), and a parent always precedes its children."""
+    from gpu_util import terrain_arrays
+    A = terrain_arrays(n=64)                                     # 8,194 triangles: ~1,700 nodes
+    nodes, order, isect = build(A, 2)
+    assert nodes.shape[0] > 341
+    level, frontier, seen = 0, [0], 0
+    expect = 0
+    while frontier and expect < 341:
+        nxt = []
+        for nid in frontier:
+            if expect < 341:
+                assert nid == expect, (level, nid, expect)       # breadth-first: ids come level by level, left to right
+            expect += 1
+            child = nodes[nid].view(np.uint32)[12:16]
+            for cw in child:
+                if (cw & 7) == 0:
+                    assert (cw >> 3) > nid
+                    nxt.append(int(cw >> 3))
+        frontier, level = nxt, level + 1
+    assert level >= 4

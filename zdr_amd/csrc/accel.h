@@ -282,20 +282,24 @@ struct BvhAccel {
     // entries on a 1 M triangle tree, 11 KiB of LDS per wave) is a worst case that real rays almost never approach,
     // and LDS is what limits the waves per CU of the BVH kernels.
     struct Fetched { float4 n0, n1, n2, n3, n4, n5; bool dead; };
+    // No slot of a Fetched is zero-filled: n0..n3 are loaded by every lane (a lane whose budget has run out reads the first records of
+    // the triangle array instead — any valid address — and consume() looks at `dead` before anything else), n4 / n5 are written only
+    // for a leaf of more than one triangle, which is exactly when consume() reads them.  Zero-filling the 24 registers cost 23 v_mov in
+    // EVERY trip of the walk (a frozen undef is materialised as a zero too): 7 % of its instructions.
     ZD static Fetched fetch(const DScene &S, int *stack, Walker &w) {
         Fetched f;
         f.dead = (--w.budget < 0);
-        f.n0 = f.n1 = f.n2 = f.n3 = f.n4 = f.n5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #ifdef ZDR_BVH_TOP_CACHE
         if ((w.cnt == 0) & (w.id < S.lds_top)) {              // the top of the tree: from this wave's LDS copy (experiment, scene.h)
             const float4 *q = top_nodes(S, stack) + 4 * w.id;
-            if (!f.dead) { f.n0 = q[0]; f.n1 = q[1]; f.n2 = q[2]; f.n3 = q[3]; }
+            f.n0 = q[0]; f.n1 = q[1]; f.n2 = q[2]; f.n3 = q[3];
             return f;
         }
 #endif
         const float4 *p = (w.cnt == 0) ? S.nodes + 4 * (size_t)w.id : S.isect + 3 * (size_t)w.id;   // isect is padded by one record
-        if (!f.dead) { f.n0 = p[0]; f.n1 = p[1]; f.n2 = p[2]; f.n3 = p[3]; }
-        if (!f.dead && w.cnt > 1) { f.n4 = p[4]; f.n5 = p[5]; }
+        if (f.dead) p = S.isect;                               // >= 2 records = 6 float4 are always there
+        f.n0 = p[0]; f.n1 = p[1]; f.n2 = p[2]; f.n3 = p[3];
+        if (w.cnt > 1) { f.n4 = p[4]; f.n5 = p[5]; }
         return f;
     }
     ZD static bool consume(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const Fetched &f, const bool anyhit) {
@@ -355,13 +359,20 @@ struct BvhAccel {
             float t;
             if (tri_test(n0, n1, n2, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id; }
             if (cnt > 1 && tri_test(n3, f.n4, f.n5, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id + 1; }
-            for (int s = id + 2; s < id + cnt; s++)       // leaves of more than two triangles (ZDR_BVH_LEAF > 2)
+#if ZDR_BVH_LEAF > 2
+            for (int s = id + 2; s < id + cnt; s++)       // leaves of more than two triangles
                 if (tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = s; }
+#endif
             if (anyhit && w.h.slot >= 0) ray_done = true;         // any-hit: the first hit settles it
         }
         if (!ray_done && w.sp != 0) {
             w.sp--;
-            int e = (w.sp < LN) ? stack[w.sp * 64 + lane] : deep[w.sp - LN];
+            // The pop is on the critical path of every trip.  Written as one conditional expression the compiler merges the LDS and the
+            // scratch access into a FLAT load (generic pointer, aperture check, vector-memory issue and latency even for the LDS case);
+            // an unconditional ds_read of a clamped entry plus a branch that is skipped unless some lane is beyond the LDS part keeps it in LDS.
+            typedef __attribute__((address_space(3))) int lds_int_t;      // an explicit LDS pointer: ds_read_b32, whatever the optimiser thinks of the scratch access next to it
+            int e = ((lds_int_t *)stack)[((w.sp < LN) ? w.sp : 0) * 64 + lane];
+            if (w.sp >= LN) e = deep[w.sp - LN];
             w.id = e >> 3; w.cnt = e & 7;
             return true;
         }

@@ -4,6 +4,10 @@
 #pragma once
 #include "vecmath.h"
 
+// largest leaf of the BVH builder (zdr_api.cpp); the walk fetches two triangles with the node fetch and loops over any further ones
+#ifndef ZDR_BVH_LEAF
+#define ZDR_BVH_LEAF 2   // 1 M triangles, path fwd / bwd ms at 1024^2 spp 32: leaf 1: 46 / 61, 2: 42 / 56, 3: 43 / 58, 4: 48 / 64, 6: 54 / 72 (a triangle costs three per-lane loads, a node four)
+#endif
 #define ZDR_BVH_STACK 64   // upper bound of per-lane traversal stack entries; the builder bounds the tree depth below it
 // of which this many live in LDS (the rest, rarely reached, in scratch), per kind of kernel: the backward kernel's waves per CU are
 // decided by LDS, the forward kernel's by VGPRs.  1 M triangles, 1024^2 spp 32, ms with 6 / 8 / 12 / 16 entries in LDS: forward

@@ -47,9 +47,7 @@ static void normal_matrix(const float *m, float *n) {      // inverse(transpose(
 #ifndef ZDR_BVH_BINS
 #define ZDR_BVH_BINS 32   // 1 M triangles, path fwd / bwd ms at 1024^2 spp 32: 16 bins 33.9 / 44.1, 32 bins 33.5 / 43.7
 #endif
-#ifndef ZDR_BVH_LEAF
-#define ZDR_BVH_LEAF 2   // 1 M triangles, path fwd / bwd ms at 1024^2 spp 32: leaf 1: 46 / 61, 2: 42 / 56, 3: 43 / 58, 4: 48 / 64, 6: 54 / 72 (a triangle costs three per-lane loads, a node four)
-#endif
+// (ZDR_BVH_LEAF lives in scene.h: the walk compiles its generic leaf loop only when leaves can hold more than two triangles)
 static_assert(ZDR_BVH_LEAF >= 1 && ZDR_BVH_LEAF <= 6, "the child word holds the leaf size in 3 bits, 7 = unused");
 #ifndef ZDR_BVH_BFS_NODES
 #define ZDR_BVH_BFS_NODES 341   // root + four levels of a full BVH4: numbered breadth-first, so that "node id < K" is the top of the tree for any K up to here

@@ -62,6 +62,7 @@ struct DScene {
     // environment light (envmap.py; heap slots 23330-23332): lat-long RGBA texture + importance tables
     const float4 *env_tex; const float *alias_prob; const int32_t *alias_idx; const float *env_pdf;
     int32_t env_count, env_h, env_w, map_w, map_h;
+    const char *walk_base; uint32_t isect_off;   // BVH: nodes[] and isect[] live in ONE allocation, nodes first; isect[] starts isect_off bytes behind walk_base
     int32_t stack_entries;          // per-lane traversal stack entries this tree needs
     int32_t lds_stack;              // how many of them this launch keeps in LDS (dynamic LDS: lds_stack x 64 ints per wave), set by the launcher
     int32_t lds_top;                // nodes [0, lds_top) — the top of the tree, numbered breadth-first by the builder — are copied into each wave's LDS behind its stack (accel.h), set by the launcher

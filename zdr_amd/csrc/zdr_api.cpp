@@ -397,6 +397,7 @@ struct zdr_scene {
     std::vector<int32_t> inst_tri_begin;
     std::vector<float> emission;
     float4 *d_isect = nullptr, *d_pairs = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
+    bool isect_in_nodes = false;            // BVH: d_isect points into the d_nodes allocation (freed once)
     uint32_t nquads = 0, nquads2 = 0, npar = 0;   // brute force: primitives of the pair walk, how many of them are merged quads (find_quads), how many of those parallelograms
     float4 *d_ppairs = nullptr;
     float *d_emission = nullptr;
@@ -569,7 +570,16 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
 
     hipError_t e = hipSuccess;
     auto up = [&](auto **dst, const void *src, size_t bytes) { if (e == hipSuccess) e = upload(dst, src, bytes, &s->device_bytes); };
-    up(&s->d_isect, isect.data(), isect.size() * sizeof(float4));
+    // BVH: nodes and plane records share ONE allocation, nodes first — the walk then addresses whatever a lane stands on as
+    // base + a 32-bit byte offset (accel.h, fetch): no 64-bit address arithmetic, no branch between "node" and "triangle" pointers.
+    const bool one_block = use_bvh;
+    if (one_block) {
+        if ((nodes.size() + isect.size()) * sizeof(float4) >= (1ull << 32)) { zdr_scene_destroy(s); return fail(ZDR_E_UNSUPPORTED, "BVH nodes and triangle records exceed 4 GiB"); }
+        std::vector<float4> both(nodes); both.insert(both.end(), isect.begin(), isect.end());
+        up(&s->d_nodes, both.data(), both.size() * sizeof(float4));
+        s->d_isect = s->d_nodes ? s->d_nodes + nodes.size() : nullptr;
+        s->isect_in_nodes = true;
+    } else up(&s->d_isect, isect.data(), isect.size() * sizeof(float4));
     if (!use_bvh) {
         // brute-force loops test two PRIMITIVES per trip with packed fp32 math, a primitive being a quad (slots 2q, 2q + 1)
         // or a single triangle: plane N of the (first) triangle and four edge functions — u and v of both triangles of a quad,
@@ -597,7 +607,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
         s->ds.nppairs = getenv("ZDR_NO_PARALLELOGRAMS") ? 0 : (int32_t)nppairs;
     }
     up(&s->d_shade, shade.data(), shade.size() * sizeof(float4));
-    up(&s->d_nodes, nodes.data(), nodes.size() * sizeof(float4));
+    if (!one_block) up(&s->d_nodes, nodes.data(), nodes.size() * sizeof(float4));
     up(&s->d_emission, s->emission.data(), s->emission.size() * sizeof(float));
     up(&s->d_light_insts, lights.data(), lights.size() * sizeof(int32_t));
     up(&s->d_inst_tri_begin, s->inst_tri_begin.data(), s->inst_tri_begin.size() * sizeof(int32_t));
@@ -612,6 +622,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     if (const char *e = getenv("ZDR_DEBUG_BVH_BUDGET")) s->ds.debug_bvh_budget = atoi(e);
     s->ds.nquads = (int32_t)s->nquads; s->ds.nquads2 = (int32_t)s->nquads2;
     s->ds.ntris = (int32_t)ntris; s->ds.ninst = (int32_t)ninst; s->ds.light_count = light_count; s->ds.nnodes = (int32_t)s->bvh_nodes; s->ds.stack_entries = (int32_t)s->stack_entries;
+    s->ds.walk_base = (const char *)(one_block ? s->d_nodes : s->d_isect); s->ds.isect_off = one_block ? (uint32_t)(nodes.size() * sizeof(float4)) : 0u;   // accel.h, fetch
     { int rc = upload_light_table(s, lights, light_count, nullptr); if (rc) { zdr_scene_destroy(s); return rc; } }
     *out = s;
     return ZDR_OK;
@@ -649,7 +660,7 @@ extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int a
 extern "C" int zdr_scene_destroy(zdr_scene *s) {
     if (!s) return ZDR_OK;
     (void)hipSetDevice(s->device);
-    (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_ppairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts); (void)hipFree(s->d_light_tris); (void)hipFree(s->d_light_range); (void)hipFree(s->d_emission4);
+    if (!s->isect_in_nodes) (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_ppairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts); (void)hipFree(s->d_light_tris); (void)hipFree(s->d_light_range); (void)hipFree(s->d_emission4);
     (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters); (void)hipFree(s->d_error);
     delete s;
     return ZDR_OK;

@@ -236,6 +236,9 @@ ZD float qbox_entry(uint32_t nxq, uint32_t nyq, uint32_t nzq, uint32_t fxq, uint
     return (tn <= tf) ? tn : 3.0e38f;
 }
 
+#ifndef ZDR_BVH_FUSED_WALK
+#define ZDR_BVH_FUSED_WALK 1
+#endif
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
     static constexpr int kMinWavesFwdEnv = ZDR_MIN_WAVES_BVH;
@@ -394,12 +397,32 @@ struct BvhAccel {
                         bool needB, f3 oB, f3 dB, float tminB, float tmaxB, bool &occ, Hit &hit, bool needA = true) {
         occ = false;
         hit.slot = -1; hit.u = 0.0f; hit.v = 0.0f; hit.t = tmaxB;
-        if (!(HAS_A && needA) && !needB) return;
         bool first = HAS_A && needA;                         // this lane is still on its any-hit ray
+        bool active = first || (HAS_B && needB);             // this lane has a ray in flight
         const int LN = S.lds_stack;
         int deep[ZDR_BVH_STACK];
         Walker w;
         if (first) start(S, w, oA, dA, tminA, tmaxA); else start(S, w, oB, dB, tminB, tmaxB);
+#if ZDR_BVH_FUSED_WALK
+        // ONE loop with a wave-uniform exit: a lane whose first ray ends starts its second ray inside the trip, under its own exec
+        // mask.  (Written as `for (;;) { if (step()) continue; ...restart...; continue; }` the compiler splits the loop in two nested
+        // ones — an inner one that runs until EVERY lane's current ray has ended, an outer one that restarts them together — and the
+        // wave's trip count becomes max(first walks) + max(second walks) instead of max(first + second): found in the ISA in round 3.)
+        while (__ballot(active) != 0ull) {
+            if (active) {
+                if (!step(S, stack, LN, deep, w, first)) {   // this lane's current ray has ended
+                    if (w.budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);   // the walk was cut short: whatever it returns is not a result
+                    if (first) {
+                        occ = w.h.slot >= 0;
+                        first = false;
+                        if (HAS_B && needB) start(S, w, oB, dB, tminB, tmaxB); else active = false;
+                    } else active = false;
+                }
+            }
+        }
+        if (HAS_B && needB) { hit = w.h; hit_barycentrics(S, hit, oB, dB); }
+#else
+        if (!active) return;
         for (;;) {
             if (step(S, stack, LN, deep, w, first)) continue;
             // this lane's current ray has ended
@@ -414,6 +437,7 @@ struct BvhAccel {
             break;
         }
         if (HAS_B && !first && needB) { hit = w.h; hit_barycentrics(S, hit, oB, dB); }
+#endif
     }
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         bool occ; Hit h;

@@ -301,7 +301,7 @@ struct BvhAccel {
 #endif
         // nodes and plane records live in one allocation (zdr_api.cpp): scalar base + 32-bit byte offset (a node is 64 bytes, a triangle 48) —
         // three VALU instead of a branch, a four-pass v_mad_i64 and 64-bit shifts and adds in every trip
-        uint32_t off = (w.cnt == 0) ? ((uint32_t)w.id << 6) : __umul24((uint32_t)w.id, 48u) + S.isect_off;
+        uint32_t off = (w.cnt == 0) ? ((uint32_t)w.id << 6) : (uint32_t)w.id * 48u + S.isect_off;
         if (f.dead) off = S.isect_off;                         // >= 2 records = 6 float4 are always there
         const float4 *p = (const float4 *)(S.walk_base + off);
         f.n0 = p[0]; f.n1 = p[1]; f.n2 = p[2]; f.n3 = p[3];

@@ -216,7 +216,7 @@ static inline int tri_intersect(const float *q, const ray_t *r, float tmax, floa
 
 /* ---- the oracle's own search structure (see struct zdro_scene) ---- */
 typedef struct { float c[3]; int32_t tri; } bprim_t;
-static int g_sort_axis;
+static __thread int g_sort_axis;   /* per thread: ctypes releases the GIL, two scenes may be built at once */
 static int cmp_prim(const void *a, const void *b) {
     float x = ((const bprim_t *)a)->c[g_sort_axis], y = ((const bprim_t *)b)->c[g_sort_axis];
     return (x > y) - (x < y);

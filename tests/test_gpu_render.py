@@ -524,3 +524,36 @@ def test_texture_optimisation_example_converges(tmp_path):
     losses = mod.run(iters=40, res=96, spp=8, tex=64, out=str(tmp_path), verbose=False)
     assert np.mean(losses[-5:]) < 0.75 * losses[0], (losses[0], losses[-5:])      # the Monte-Carlo noise of an 8-spp render sets the floor
     assert os.path.exists(tmp_path / "result.png") and os.path.exists(tmp_path / "footprints.png")
+
+
+def test_render_calls_can_be_captured_in_a_hip_graph(mat_a):
+    """The C-ABI only enqueues on the stream it is given (no synchronise, no allocation after the first call of a kind, workspaces
+    owned by the handle), so a forward + backward pair can be captured once in a HIP graph (torch.cuda.CUDAGraph on ROCm) and replayed:
+    small renders in an optimisation loop are launch-bound (four launches per pass).  Kernel arguments — seed included — are frozen at
+    capture; material, cotangent, image and gradient are read / written in place on every replay."""
+    scene = make_scene("path")
+    m = torch.from_numpy(mat_a).cuda()
+    W, H, spp, seed = 64, 48, 16, 9
+    cot = torch.ones((H, W, 4), device="cuda")
+    img = torch.zeros((H, W, 4), device="cuda"); g = torch.zeros_like(m)
+    # warm up on a side stream: first-use allocations of the handle's workspaces, tile masks, occupancy queries
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        scene.render_forward(m, (W, H), spp, seed, out=img)
+        scene.render_backward(cot, g, m, (W, H), spp, seed)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    ref_img, ref_g = img.clone(), g.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        scene.render_forward(m, (W, H), spp, seed, out=img)
+        g.zero_()
+        scene.render_backward(cot, g, m, (W, H), spp, seed)
+    for scale in (1.0, 0.5):                                     # replay on changed inputs: the graph reads them in place
+        img.zero_(); cot.fill_(scale)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(img, ref_img)
+        torch.testing.assert_close(g, ref_g * scale, rtol=1e-4, atol=1e-6 * float(ref_g.abs().max()))
+    scene.check()

@@ -53,6 +53,7 @@ struct KernelIO {
 
 int zdr_launch_render(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io,
                       int integrator, int accel_is_bvh, int backward, int stats, hipStream_t stream);
+int zdr_launch_zero(void *p, size_t bytes, hipStream_t stream);   // kernel zero-fill (graph-safe, see zdr_kernels.hip)
 int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *rays, uint32_t n,
                      int32_t *out_i, float *out_f, hipStream_t stream);
 int zdr_launch_sampler_dump(const SamplerCfg &C, const int32_t *queries, uint32_t n, int32_t nvert,

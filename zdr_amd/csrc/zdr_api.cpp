@@ -844,7 +844,7 @@ static int ensure_ring(zdr_scene *s, hipStream_t st) {
         s->ring_bytes = need;
     }
     if (!s->d_work_counters) HIPCHK(hipMalloc((void **)&s->d_work_counters, 8 * sizeof(unsigned int)));
-    HIPCHK(hipMemsetAsync(s->d_work_counters, 0, 8 * sizeof(unsigned int), st));
+    if (zdr_launch_zero(s->d_work_counters, 8 * sizeof(unsigned int), st)) return fail(ZDR_E_HIP, "zero-fill launch failed");
     return ZDR_OK;
 }
 
@@ -855,7 +855,7 @@ static int ensure_cells(zdr_scene *s, const RenderCfg &R, hipStream_t st) {
         HIPCHK(hipMalloc((void **)&s->d_cells, need));
         s->cells_bytes = need;
     }
-    HIPCHK(hipMemsetAsync(s->d_cells, 0, need, st));
+    if (zdr_launch_zero(s->d_cells, need, st)) return fail(ZDR_E_HIP, "zero-fill launch failed");
     return ZDR_OK;
 }
 

@@ -580,6 +580,21 @@ __global__ void k_reduce_chunks(RenderCfg R, uint32_t spp, const float4 *partial
     image[pix] = make_float4(__fdiv_rn(s.x, fs), __fdiv_rn(s.y, fs), __fdiv_rn(s.z, fs), R.alpha);
 }
 
+// Zero-fill of the per-call workspaces (staging cells, work counters) by a KERNEL, not hipMemsetAsync: captured in a HIP graph, the
+// runtime's memset node of the 64 MiB cell array was observed to run out of order with the kernels around it from the second replay on
+// (the gradient came back zero); a kernel node is ordered like every other launch.  n16 = number of 16-byte words.
+__global__ void k_zero(uint4 *__restrict__ p, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+int zdr_launch_zero(void *p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    const size_t n16 = (bytes + 15) / 16;                    // every workspace is allocated in multiples of 16 bytes
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_zero, dim3(blocks), dim3(256), 0, st, (uint4 *)p, n16);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ----------------------------------------------------------------------------------- launch
 // dynamic LDS of a wave that traverses the BVH: the first entries of the per-lane stacks (accel.h).  Sets S.lds_stack.
 static size_t bvh_dyn_lds(DScene &S, bool backward) {

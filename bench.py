@@ -55,9 +55,10 @@ def visible_gpu_count():
     node with SIMDs; HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES narrow it.  None when the topology cannot be read (the ranks
     then fail on their own if a device is missing)."""
     n = 0
-    if not os.path.isdir("/sys/class/kfd"):
+    root = os.environ.get("ZDR_KFD_ROOT", "/sys/class/kfd")       # (the override exists for tests/test_bench_cli.py)
+    if not os.path.isdir(root):
         return 0                                                # no amdgpu compute driver at all
-    props = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    props = glob.glob(os.path.join(root, "kfd/topology/nodes/*/properties"))
     if not props:
         return None
     for path in props:

@@ -10,7 +10,8 @@
  * of the reference's Python/LuisaCompute-DSL source, function by function, with
  * file:line citations into /root/reference.  It is pinned instead by closed-form
  * known-answer tests, float64 NumPy re-evaluations and finite differences
- * (tests/test_oracle_*.py).
+ * (tests/test_oracle_*.py).  (The one reference module that does run here, load_obj.py, has no counterpart
+ * in this file: it pins the product's OBJ ingest directly, tests/golden/obj_fixtures.npz.)
  */
 #ifndef ZDR_ORACLE_H
 #define ZDR_ORACLE_H

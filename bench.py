@@ -252,6 +252,9 @@ def pmc_fields(roof, kernel, cfg, stats, active):
                 roof["valu_issue_frac"] = round(rec["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), 4)    # busy cycles summed over the SIMDs: x4 per wave64 instruction, 1024 SIMDs
             if rec.get("valu_lane_utilisation"):
                 roof["lane_utilisation"] = round(rec["valu_lane_utilisation"], 4)
+            if rec.get("SQ_WAVES"):                            # persistent kernel: the launch IS the resident set, one wave per workgroup
+                roof["waves_per_simd"] = round(rec["SQ_WAVES"] / 1024.0, 2)
+                roof["wavefront_occupancy"] = round(rec["SQ_WAVES"] / 1024.0 / 8.0, 3)   # of the 8 wave slots per SIMD of gfx950
             if rec.get("atomic_requests") and stats.get("shaded_vertices"):
                 roof["atomic_requests_per_vertex"] = round(rec["atomic_requests"] / stats["shaded_vertices"], 4)
             roof["measured_bound"] = rec.get("measured_bound", "valu_issue")

@@ -531,6 +531,9 @@ def test_render_calls_can_be_captured_in_a_hip_graph(mat_a):
     owned by the handle), so a forward + backward pair can be captured once in a HIP graph (torch.cuda.CUDAGraph on ROCm) and replayed.
     Kernel arguments — seed included — are frozen at
     capture; material, cotangent, image and gradient are read / written in place on every replay."""
+    import os
+    if os.environ.get("ZDR_CHECK", "0") not in ("", "0"):
+        pytest.skip("ZDR_CHECK=1 synchronises inside every render call: such a call cannot be captured")
     scene = make_scene("path")
     m = torch.from_numpy(mat_a).cuda()
     W, H, spp, seed = 64, 48, 16, 9
@@ -562,8 +565,11 @@ def test_render_calls_can_be_captured_in_a_hip_graph(mat_a):
 def test_captured_render_matches_eager_and_follows_the_material(mat_a):
     """zdr_amd.graph.capture: one HIP-graph replay = forward + backward of the captured view; the material is read in place, so an
     in-place update is seen by the next replay."""
+    import os
     import time
     from zdr_amd import graph
+    if os.environ.get("ZDR_CHECK", "0") not in ("", "0"):
+        pytest.skip("ZDR_CHECK=1 synchronises inside every render call: such a call cannot be captured")
     scene = make_scene("path")
     m = torch.from_numpy(mat_a).cuda()
     W, H, spp, seed = 64, 64, 16, 3

@@ -11,7 +11,7 @@ kernels themselves (tests/test_gpu_render.py::test_captured_render_matches_eager
         ...                                         # update material in place (e.g. an optimiser step on the same storage)
 
 Kernel arguments are frozen at capture — the seed among them: every replay renders the same sample set (a fixed-seed
-objective; capture again for another seed).  One capture per scene handle may be replayed at a time (include/zdr.h: one call in
+objective; capture again for another seed).  Not under ZDR_CHECK=1, which synchronises inside every call.  One capture per scene handle may be replayed at a time (include/zdr.h: one call in
 flight per handle).
 """
 from __future__ import annotations

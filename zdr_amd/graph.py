@@ -3,7 +3,7 @@
 libzdr_hip.so only enqueues on the stream it is given and allocates nothing after the first call of a kind, so a forward + backward
 pair (about eight launches) can be captured; a replay is ONE launch from the host.  What it buys is a free host thread, not GPU time:
 measured on one MI355X at 64 x 64 x 16 spp, eager 0.667 ms and captured 0.676 ms per step — even that small a pass is bound by the
-kernels themselves (tests/test_gpu_render.py::test_captured_render_matches_eager_and_follows_the_material prints both).
+kernels themselves (tests/test_zz_gpu_graph.py::test_captured_render_matches_eager_and_follows_the_material prints both).
 
     step = zdr_amd.graph.capture(scene, material, res=(64, 64), spp=16, seed=0)
     for it in range(1000):

@@ -174,8 +174,37 @@ struct ItemBanks {
     uint32_t inflight[2];    // parked + running paths of each bank (wave-uniform)
 };
 
+// ZDR_KARG_RELOAD (experiment): the persistent kernels read their launch constants (scene pointers, camera, sampler grid ...)
+// through a pointer to the kernarg segment that is laundered once per trip, so a constant is s_load-ed again where a trip uses it
+// instead of being kept for the whole kernel in an SGPR that is spilled to a VGPR lane (v_readlane / v_writelane / s_nop on the
+// VALU port, 320 reloads in k_path<cmj, brute>).
+#ifndef ZDR_KARG_RELOAD
+#define ZDR_KARG_RELOAD 1
+#endif
+struct PathKArgs { DScene S; RenderCfg R; SamplerCfg C; KernelIO io; };
+typedef __attribute__((address_space(4))) const char karg_byte_t;
+ZD const PathKArgs &kargs_fresh() {
+    karg_byte_t *p = (karg_byte_t *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const PathKArgs *)p;
+}
+#if ZDR_KARG_RELOAD
+#define ZDR_KARGS_BEGIN const PathKArgs *ka = &kargs_fresh();
+#define ZDR_KARGS_REFRESH ka = &kargs_fresh();
+#else
+#define ZDR_KARGS_BEGIN const DScene &S = S_; const RenderCfg &R = R_; const SamplerCfg &C = C_; const KernelIO &io = io_;
+#define ZDR_KARGS_REFRESH
+#endif
+
 template <int SK, class A, bool STATS, bool ENV>
-__global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) void k_path(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) void k_path(DScene S_, RenderCfg R_, SamplerCfg C_, KernelIO io_) {
+    ZDR_KARGS_BEGIN
+#if ZDR_KARG_RELOAD
+#define S (ka->S)
+#define R (ka->R)
+#define C (ka->C)
+#define io (ka->io)
+#endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ uint32_t lds_perm[2 * WAVE];
     __shared__ int lds_origin[4];
@@ -201,6 +230,7 @@ __global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) v
     it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
     int stall = 0;
     for (;;) {
+        ZDR_KARGS_REFRESH
         bool progress = false;
         if (q.tail - q.head < (uint32_t)__popcll(__ballot(!alive))) {          // the FIFO cannot serve every idle lane
             if (next_sample < s_end) {
@@ -271,6 +301,12 @@ __global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) v
         if (stall > 4) { raise_device_error(S, ZDR_DEVERR_STALL); break; }   // cannot happen (every branch above makes progress); never spin on the GPU, never end silently
     }
     flush_counters<STATS>(io, cnt);
+#if ZDR_KARG_RELOAD
+#undef S
+#undef R
+#undef C
+#undef io
+#endif
 }
 
 // PRB backward with ONE traversal.  Each trip a live lane shades one vertex of its path (same trip
@@ -282,7 +318,14 @@ __global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) v
 // Keeping the records out of scratch is what matters: 2.3 KB of scratch per lane thrashed L2 (113 GB of
 // fabric traffic per launch, 13 of 37 ms).
 template <int SK, class A, bool ENV>
-__global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, RenderCfg R_, SamplerCfg C_, KernelIO io_) {
+    ZDR_KARGS_BEGIN
+#if ZDR_KARG_RELOAD
+#define S (ka->S)
+#define R (ka->R)
+#define C (ka->C)
+#define io (ka->io)
+#endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
     constexpr int LV = A::kLdsVertices;                     // vertex records kept in LDS (the others go to scratch)
@@ -322,6 +365,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
     unsigned long long st_trips = 0, st_shaded = 0, st_fin = 0, st_iters = 0, st_steps = 0;
 #endif
     for (;;) {
+        ZDR_KARGS_REFRESH
         bool progress = false;
         if (pq.tail - pq.head < (uint32_t)__popcll(__ballot(!alive))) {
             if (next_sample < s_end) {
@@ -454,6 +498,12 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S, Re
         atomicAdd(io.counters + 5, q.st_flushes); atomicAdd(io.counters + 6, q.st_entries); atomicAdd(io.counters + 7, q.st_dups);
     }
 #endif
+#if ZDR_KARG_RELOAD
+#undef S
+#undef R
+#undef C
+#undef io
+#endif
 }
 
 // ---------------------------------------------------------------------- direct / collocated
@@ -462,7 +512,14 @@ template <int INTEG, int SK, class A, bool BWD, bool STATS, bool ENV>
 #define ZDR_MIN_WAVES_DIRECT 4   // brute-force direct kernels, cbox 512^2 spp 64: 153 VGPRs (3 waves per SIMD) 1.175 / 1.331 ms, 128 VGPRs (6 spilled) 1.110 / 1.267 ms
 #endif
 // (the environment instantiations take 170 VGPRs: bounded to 3 waves per SIMD, which costs no spill, instead of the 2 the compiler settles for)
-__global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV ? 3 : ZDR_MIN_WAVES_DIRECT) : 1) void k_simple(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
+__global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV ? 3 : ZDR_MIN_WAVES_DIRECT) : 1) void k_simple(DScene S_, RenderCfg R_, SamplerCfg C_, KernelIO io_) {
+    ZDR_KARGS_BEGIN
+#if ZDR_KARG_RELOAD
+#define S (ka->S)
+#define R (ka->R)
+#define C (ka->C)
+#define io (ka->io)
+#endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 1];
     A::prepare(S, lds);
@@ -477,6 +534,7 @@ __global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV
     const unsigned long long cam_mask = camera_mask(S, io, w);
     f3 sum = mk3(0.0f);
     for (uint32_t it = w.s_begin; it < w.s_end; it++) {     // integrator.py:15 (wave-uniform trip count)
+        ZDR_KARGS_REFRESH
         float4 grad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         f2 guv; guv.x = 0.0f; guv.y = 0.0f;
         if (w.valid) {
@@ -494,6 +552,12 @@ __global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV
     if (BWD) scatter_finish(q, io.cells);
     if (!BWD && !STATS) store_pixel(R, C, io, w, sum);
     flush_counters<STATS>(io, cnt);
+#if ZDR_KARG_RELOAD
+#undef S
+#undef R
+#undef C
+#undef io
+#endif
 }
 
 // Folds the staging cells into the gradient texture: texel (x, y) receives corner (dx, dy) of every

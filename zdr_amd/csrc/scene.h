@@ -132,7 +132,7 @@ ZD float4 read_bsdf(const float4 *__restrict__ mat, f2 uv, int tex_h, int tex_w)
 //    [corner m = 2*dx + dy][channel].  k_cells_to_grad then gathers, per texel, the (up to four)
 //    cells whose footprint covers it.  CLAMP addressing folds out-of-range bases onto the border
 //    cells, which is exact because the clamped corners coincide (weights sum to the same texel).
-//  * Per-wavefront LDS queue, transposed flush.  Lanes push (cell, g, ox, oy); on flush 16 lanes
+//  * Per-wavefront LDS queue, transposed flush.  Lanes push (g, uv); on flush 16 lanes
 //    serve one vertex (lane j adds float j of the cell), so a wave instruction carries four whole
 //    64-byte cells instead of 64 unrelated dwords: one atomic request per vertex instead of 16.
 #ifndef ZDR_SCATTER_CAP
@@ -190,11 +190,31 @@ ZD ScatterQueue scatter_queue_init(float *lds, int tex_h, int tex_w, int cell_co
     return q;
 }
 
-// must be called by the whole wave (reconverged control flow)
-ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells) {
+// Footprint of a gradient at uv: base cell (clamped so that out-of-range bases fold onto the border cells) and the bilinear offsets.
+ZD int scatter_cell(f2 uv, int tex_h, int tex_w, float &ox, float &oy) {
+    float px = uv.x * (float)(tex_w - 1), py = (1.0f - uv.y) * (float)(tex_h - 1);   // interaction.py:78-80
+    int ix = (int)px, iy = (int)py;
+    ox = px - (float)ix; oy = py - (float)iy;
+    int cx = clampi(ix, -1, tex_w - 1) + 1, cy = clampi(iy, -1, tex_h - 1) + 1;
+    return cx + (tex_w + 1) * cy;
+}
+
+// must be called by the whole wave (reconverged control flow).  The queue holds (g, uv) as pushed; the flush first turns the uv of
+// all its entries into (cell, ox, oy) — lane = entry, once per ~57 entries instead of once per push (5.45 pushes per trip of the
+// backward path kernel, each by the whole wave for the few lanes that hold a gradient) — then adds them, 16 lanes per entry.
+ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells, int tex_h, int tex_w, int ablate) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int lane = threadIdx.x & 63, sub = lane >> 4, j = lane & 15;
+    for (int e = lane; e < q.count; e += 64) {
+        f2 uv; uv.x = q.ox[e]; uv.y = q.oy[e];
+        float ox, oy;
+        const int cell = scatter_cell(uv, tex_h, tex_w, ox, oy);
+        q.cell[e] = (ablate == 2) ? (cell & 1023) : (q.copy_base + cell);   // ablation 2: all atomics hit 64 KiB of L2
+        q.ox[e] = ox; q.oy[e] = oy;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #ifdef ZDR_BWD_STATS
     if (q.count > 0) {
         bool dup = false;
@@ -218,8 +238,8 @@ ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells) {
 }
 
 // end of the kernel: whatever is still queued, and the LDS cell array if the wave kept one
-ZD void scatter_finish(ScatterQueue &q, float *__restrict__ cells) {
-    scatter_flush(q, cells);
+ZD void scatter_finish(ScatterQueue &q, float *__restrict__ cells, int tex_h, int tex_w, int ablate) {
+    scatter_flush(q, cells, tex_h, tex_w, ablate);
     if (q.lds_cells) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -236,13 +256,10 @@ ZD void scatter_push(ScatterQueue &q, float *__restrict__ cells, bool active, f2
     unsigned long long mask = __ballot(active);
     int n = __popcll(mask);
     if (n == 0) return;
-    float px = uv.x * (float)(tex_w - 1), py = (1.0f - uv.y) * (float)(tex_h - 1);   // interaction.py:78-80
-    int ix = (int)px, iy = (int)py;
-    float ox = px - (float)ix, oy = py - (float)iy;
-    int cx = clampi(ix, -1, tex_w - 1) + 1, cy = clampi(iy, -1, tex_h - 1) + 1;
-    const int cell = cx + (tex_w + 1) * cy;
     if (q.lds_cells) {                   // few texels: the cell array is in LDS, 16 ds_add_f32 per vertex
         if (active) {
+            float ox, oy;
+            const int cell = scatter_cell(uv, tex_h, tex_w, ox, oy);
             float *c = q.lds_cells + 16 * cell;
             const float k00 = (1.0f - ox) * (1.0f - oy), k01 = (1.0f - ox) * oy, k10 = ox * (1.0f - oy), k11 = ox * oy;   // corner m = 2 dx + dy
             const float gg[4] = {g.x, g.y, g.z, g.w}, kk[4] = {k00, k01, k10, k11};
@@ -253,15 +270,14 @@ ZD void scatter_push(ScatterQueue &q, float *__restrict__ cells, bool active, f2
         }
         return;
     }
-    if (q.count + n > ZDR_SCATTER_CAP) scatter_flush(q, cells);
+    if (q.count + n > ZDR_SCATTER_CAP) scatter_flush(q, cells, tex_h, tex_w, ablate);
     if (active) {
         int slot = q.count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        q.cell[slot] = (ablate == 2) ? (cell & 1023) : (q.copy_base + cell);   // ablation 2: all atomics hit 64 KiB of L2
-        q.g[4 * slot] = g.x; q.g[4 * slot + 1] = g.y; q.g[4 * slot + 2] = g.z; q.g[4 * slot + 3] = g.w;
-        q.ox[slot] = ox; q.oy[slot] = oy;
+        *(float4 *)(q.g + 4 * slot) = g;
+        q.ox[slot] = uv.x; q.oy[slot] = uv.y;      // raw uv: the flush turns it into cell and offsets
     }
     q.count += n;
-    if (q.count >= ZDR_SCATTER_FLUSH_AT) scatter_flush(q, cells);
+    if (q.count >= ZDR_SCATTER_FLUSH_AT) scatter_flush(q, cells, tex_h, tex_w, ablate);
 }
 
 // ------------------------------------------------------------------------------------ lights

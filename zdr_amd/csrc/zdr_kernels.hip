@@ -14,9 +14,6 @@
 #include "zdr.h"
 
 #define WAVE 64
-#ifndef ZDR_SWEEP_PINGPONG
-#define ZDR_SWEEP_PINGPONG 0   // 1: the backward sweep loop unrolled by two with swapped record registers — measured SLOWER (14.33 vs 14.14 ms: 153 instead of 146 VGPRs and twice the loop body outweigh the 20 v_mov saved per step; profiles/r3_bwd_sweep_ablation.txt)
-#endif
 // __launch_bounds__ second argument = minimum waves per SIMD (caps the VGPR budget at 512 / n).
 // Measured on cbox 512^2 spp 256 (profiles/r1_ab_flags.txt): 3 (<= 168 VGPRs, no spills) is best for both.
 
@@ -327,7 +324,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
 #define io (ka->io)
 #endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
-    __shared__ float lds_q[ZDR_SCATTER_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds_q[ZDR_SCATTER_LDS_FLOATS];   // the queue writes g as one float4
     constexpr int LV = A::kLdsVertices;                     // vertex records kept in LDS (the others go to scratch)
     __shared__ float4 lds_rec[LV * 4 * WAVE];
     __shared__ float lds_dlnp[LV * WAVE];
@@ -440,48 +437,42 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
             ib.inflight[0] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 0));
             ib.inflight[1] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 1));
             // wave-uniform: sweep every finished path to its first vertex.  The sweep starts from the vertex packed this
-            // trip (still in registers) and the record of the NEXT step is fetched before the current one is processed, so
-            // that a scratch read (records beyond the LDS ones) is under way while the gradient is computed and queued.
+            // trip (still in registers).
             PackedVertex cur = plast;
 #ifdef ZDR_BWD_STATS   // measurement build (tools/bwd_stats.py): how full are the trips and the sweep iterations
             st_trips++; st_shaded += (unsigned long long)__popcll(__ballot(alive || done));
             st_fin += (unsigned long long)__popcll(__ballot(sw_k >= 0));
 #endif
             int sweep_cap = (R.debug_no_scatter == 4) ? 2 : ((R.debug_no_scatter == 5) ? 1 : 64);   // timing-only ablations 4 / 5: the sweep loop cut after 2 / 1 iterations
-            // One step: the record of the NEXT step is fetched into `fill` while `use` is consumed (the loop runs 5.45 times per
-            // trip at 18 % of the lanes, profiles/r3_bwd_sweep_ablation.txt).
-            auto sweep_step = [&](const PackedVertex &use, PackedVertex &fill) {
+            // One step consumes `cur`, then fetches the record of the NEXT step into the same registers and only then queues the
+            // gradient: the fetch (LDS, or scratch beyond the LDS records) is under way while the push runs, and no record is copied
+            // (the loop runs 5.45 times per trip at 18 % of the lanes, profiles/r3_bwd_sweep_ablation.txt; fetching one step ahead
+            // into a second register set cost 24 v_mov per iteration, and unrolling by two
+            // with the sets swapping roles was slower still: profiles/r3_bwd_sweep_ablation.txt section 3).
+            while (__ballot(sw_k >= 0) != 0ull && sweep_cap-- > 0) {
                 const bool swp = sw_k >= 0;
 #ifdef ZDR_BWD_STATS
                 st_iters++; st_steps += (unsigned long long)__popcll(__ballot(swp));
 #endif
-                if (swp && sw_k >= 1) {
-                    const int k = sw_k - 1;
-                    if (k < lds_vertices) {
-                        const float4 *r = lds_rec + (k * 4) * WAVE + lane;
-                        fill.a = r[0]; fill.b = r[WAVE]; fill.c = r[2 * WAVE]; fill.d = r[3 * WAVE];
-                        fill.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[k * WAVE + lane]);
-                    } else fill = deep[k];
-                }
                 float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 f2 guv; guv.x = 0.0f; guv.y = 0.0f;
-                if (swp) { g = sweep_vertex(use, sw, guv); sw_k--; }
+                if (swp) { g = sweep_vertex(cur, sw, guv); sw_k--; }
+                // everything that reads `cur` is finished here, before the fetch below overwrites it (left alone the compiler sinks
+                // part of the step below the fetch, loads into a second register set and copies — with a wait in front of the copies)
+                asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), "+v"(guv.x), "+v"(guv.y), "+v"(sw.A.x), "+v"(sw.A.y), "+v"(sw.A.z),
+                             "+v"(sw.Lv.x), "+v"(sw.Lv.y), "+v"(sw.Lv.z), "+v"(sw.s), "+v"(sw.Z), "+v"(sw.tw) : : "memory");
+                const bool fetch = swp && sw_k >= 0;
+                if (fetch && sw_k < lds_vertices) {
+                    const float4 *r = lds_rec + (sw_k * 4) * WAVE + lane;
+                    cur.a = r[0]; cur.b = r[WAVE]; cur.c = r[2 * WAVE]; cur.d = r[3 * WAVE];
+                    cur.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[sw_k * WAVE + lane]);
+                }
+                // LDS first: both kinds of fetch write the same registers (for different lanes), and the second kind waits for the
+                // first to land — an LDS read is back in ~100 cycles, a scratch read in ~500
+                asm volatile("" ::: "memory");
+                if (fetch && sw_k >= lds_vertices) cur = deep[sw_k];
                 scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
-            };
-#if ZDR_SWEEP_PINGPONG
-            PackedVertex nxt = plast;
-            while (__ballot(sw_k >= 0) != 0ull && sweep_cap-- > 0) {
-                sweep_step(cur, nxt);
-                if (__ballot(sw_k >= 0) == 0ull || sweep_cap-- <= 0) break;
-                sweep_step(nxt, cur);
             }
-#else
-            while (__ballot(sw_k >= 0) != 0ull && sweep_cap-- > 0) {
-                PackedVertex nxt = cur;
-                sweep_step(cur, nxt);
-                cur = nxt;
-            }
-#endif
         }
 #pragma unroll
         for (int b = 0; b < 2; b++)                         // an item whose samples are all generated and whose paths have ended frees its bank
@@ -490,7 +481,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
         stall = progress ? 0 : stall + 1;
         if (stall > 4) { raise_device_error(S, ZDR_DEVERR_STALL); break; }   // cannot happen (every branch above makes progress); never spin on the GPU, never end silently
     }
-    scatter_finish(q, io.cells);
+    scatter_finish(q, io.cells, R.tex_h, R.tex_w, R.debug_no_scatter);
 #ifdef ZDR_BWD_STATS
     if (lane == 0) {
         atomicAdd(io.counters + 0, st_trips); atomicAdd(io.counters + 1, st_shaded); atomicAdd(io.counters + 2, st_fin);
@@ -521,7 +512,7 @@ __global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV
 #define io (ka->io)
 #endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
-    __shared__ float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 1];
+    __shared__ __attribute__((aligned(16))) float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 4];
     A::prepare(S, lds);
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
@@ -549,7 +540,7 @@ __global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV
         }
         if (BWD) scatter_push(q, io.cells, w.valid && any_nonzero4(grad) && !any_nan4(grad), guv, grad, R.tex_h, R.tex_w, R.debug_no_scatter);
     }
-    if (BWD) scatter_finish(q, io.cells);
+    if (BWD) scatter_finish(q, io.cells, R.tex_h, R.tex_w, R.debug_no_scatter);
     if (!BWD && !STATS) store_pixel(R, C, io, w, sum);
     flush_counters<STATS>(io, cnt);
 #if ZDR_KARG_RELOAD

@@ -62,6 +62,26 @@ __global__ __launch_bounds__(64) void k(float *out, float a, float b, int iters)
                 asm volatile("s_mov_b64 s[20:21], exec\n v_cmpx_lt_f32 vcc, %0, %1\n v_cmpx_lt_f32 vcc, %2, %3\n v_cmpx_lt_f32 vcc, %4, %5\n"
                              "v_mov_b32 %6, %7\n v_mov_b32 %0, %2\n s_mov_b64 exec, s[20:21]\n v_add_f32 %1, %1, %3\n v_add_f32 %5, %5, %3\n v_add_f32 %4, %4, %3\n"
                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : : "vcc", "s20", "s21");
+            } else if (KIND == 13) {  // v_pk_mul_lo_u16: two 16-bit products per lane (the CMJ hash only needs the low bits of its state)
+                asm volatile("v_pk_mul_lo_u16 %0, %0, %8\n v_pk_mul_lo_u16 %1, %1, %8\n v_pk_mul_lo_u16 %2, %2, %8\n v_pk_mul_lo_u16 %3, %3, %8\n"
+                             "v_pk_mul_lo_u16 %4, %4, %8\n v_pk_mul_lo_u16 %5, %5, %8\n v_pk_mul_lo_u16 %6, %6, %8\n v_pk_mul_lo_u16 %7, %7, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a));
+            } else if (KIND == 14) {  // v_pk_lshrrev_b16 / v_pk_add_u16 pairs
+                asm volatile("v_pk_lshrrev_b16 %0, 3, %0\n v_pk_add_u16 %1, %1, %0\n v_pk_lshrrev_b16 %2, 3, %2\n v_pk_add_u16 %3, %3, %2\n"
+                             "v_pk_lshrrev_b16 %4, 3, %4\n v_pk_add_u16 %5, %5, %4\n v_pk_lshrrev_b16 %6, 3, %6\n v_pk_add_u16 %7, %7, %6\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            } else if (KIND == 15) {  // v_perm_b32 (byte shuffle of two registers)
+                asm volatile("v_perm_b32 %0, %0, %1, %8\n v_perm_b32 %1, %1, %2, %8\n v_perm_b32 %2, %2, %3, %8\n v_perm_b32 %3, %3, %4, %8\n"
+                             "v_perm_b32 %4, %4, %5, %8\n v_perm_b32 %5, %5, %6, %8\n v_perm_b32 %6, %6, %7, %8\n v_perm_b32 %7, %7, %0, %8\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a));
+            } else if (KIND == 16) {  // v_and_b32 / v_bitop3_b32 pairs
+                asm volatile("v_and_b32 %0, %0, %1\n v_bitop3_b32 %1, %1, %2, %3 bitop3:0x78\n v_and_b32 %2, %2, %3\n v_bitop3_b32 %3, %3, %4, %5 bitop3:0x78\n"
+                             "v_and_b32 %4, %4, %5\n v_bitop3_b32 %5, %5, %6, %7 bitop3:0x78\n v_and_b32 %6, %6, %7\n v_bitop3_b32 %7, %7, %0, %1 bitop3:0x78\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            } else if (KIND == 17) {  // the hash's pattern: v_mul_lo_u32 feeding v_xor / v_and / v_lshrrev (dependent chain, one state)
+                asm volatile("v_mul_lo_u32 %0, %0, %2\n v_and_b32 %1, 0xff, %0\n v_lshrrev_b32 %1, 2, %1\n v_xor_b32 %0, %0, %1\n"
+                             "v_mul_lo_u32 %0, %0, %2\n v_and_b32 %1, 0xff, %0\n v_lshrrev_b32 %1, 2, %1\n v_xor_b32 %0, %0, %1\n"
+                             : "+v"(x0), "+v"(x1) : "s"(a));
             } else if (KIND == 6) {   // dependent chain: one accumulator
                 asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
                              "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
@@ -106,5 +126,10 @@ int main() {
     run<10>("v_min3_f32", out, nsimd, mhz, 8);
     run<11>("v_pk_mul/add_f32, sgpr pair + op_sel", out, nsimd, mhz, 8);
     run<12>("3 v_cmpx + 2 v_mov + 3 v_add (8 VALU, 2 SALU)", out, nsimd, mhz, 8);
+    run<13>("v_pk_mul_lo_u16", out, nsimd, mhz, 8);
+    run<14>("v_pk_lshrrev_b16 / v_pk_add_u16", out, nsimd, mhz, 8);
+    run<15>("v_perm_b32", out, nsimd, mhz, 8);
+    run<16>("v_and_b32 / v_bitop3_b32", out, nsimd, mhz, 8);
+    run<17>("hash chain: mul_lo, and, lshr, xor (dependent)", out, nsimd, mhz, 8);
     return 0;
 }

@@ -34,7 +34,7 @@ struct RenderCfg {
     float inv_spp;                             // 1 / spp as computed by IEEE division
     float alpha;                               // (sample_end - sample_begin) / spp
     float cam_o[3], cam_fwd[3], cam_right[3], cam_upp[3], cam_tan;   // camera.py:12-15
-    int32_t debug_no_scatter;         // timing-only ablations (env ZDR_DEBUG_NO_SCATTER): 1 gradients computed, not added; 2 atomics confined to 64 KiB; 3 no sweep; 4 / 5 the sweep loop cut after 2 / 1 iterations (the tail of long paths dropped: what any scheme that defers it could save at most)
+    int32_t debug_no_scatter;         // timing-only ablations (env ZDR_DEBUG_NO_SCATTER): 1 gradients computed, not added; 2 atomics confined to 64 KiB; 3 no sweep; 4 / 5 the sweep loop cut after 2 / 1 iterations (the tail of long paths dropped: what any scheme that defers it could save at most); 6 queue and flush run, no atomic is issued; 7 / 8 records beyond the LDS ones not read back / not written either
 };
 
 struct KernelIO {

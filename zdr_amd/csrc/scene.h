@@ -230,7 +230,9 @@ ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells, int tex_h, int
             float ox = q.ox[e], oy = q.oy[e];
             float wx = (j & 8) ? ox : 1.0f - ox;        // corner m = j >> 2: bit 1 -> x + 1, bit 0 -> y + 1
             float wy = (j & 4) ? oy : 1.0f - oy;
-            unsafeAtomicAdd(cells + 16 * (size_t)cell + j, (wx * wy) * gc);   // k_m * dmat.c, interaction.py:82-89
+            const float add = (wx * wy) * gc;                                  // k_m * dmat.c, interaction.py:82-89
+            if (ablate == 6) asm volatile("" ::"v"(add), "v"(cell));          // ablation 6: the whole queue and flush, but no atomic is issued
+            else unsafeAtomicAdd(cells + 16 * (size_t)cell + j, add);
         }
     }
     __builtin_amdgcn_wave_barrier();

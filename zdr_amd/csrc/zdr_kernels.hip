@@ -422,7 +422,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                         float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
                         r[0] = plast.a; r[WAVE] = plast.b; r[2 * WAVE] = plast.c; r[3 * WAVE] = plast.d;
                         lds_dlnp[nrec * WAVE + lane] = plast.e.w;
-                    } else deep[nrec] = plast;
+                    } else if (R.debug_no_scatter != 8) deep[nrec] = plast;   // ablation 8: not written either
                 }
                 nrec++;
                 if (done) {
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                 // LDS first: both kinds of fetch write the same registers (for different lanes), and the second kind waits for the
                 // first to land — an LDS read is back in ~100 cycles, a scratch read in ~500
                 asm volatile("" ::: "memory");
-                if (fetch && sw_k >= lds_vertices) cur = deep[sw_k];
+                if (fetch && sw_k >= lds_vertices && R.debug_no_scatter != 7 && R.debug_no_scatter != 8) cur = deep[sw_k];   // ablations 7 / 8: deep records not read back (wrong gradients)
                 scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
             }
         }

@@ -25,6 +25,9 @@
 #define ZDR_MIN_WAVES_BWD_BVH 4
 #endif
 // vertex records of the backward kernel kept in LDS (4.25 KiB per wave each)
+#ifndef ZDR_POOL_EXTRA_BYTES
+#define ZDR_POOL_EXTRA_BYTES 200   // LDS the record pool of the brute-force backward kernel takes beyond the ZDR_LDS_VERTICES rows: gfx950 hands out LDS in 1,280-byte blocks (128 per CU), 12 waves per CU = 10 blocks = 12,800 bytes per wave, and the kernel holds 12,784
+#endif
 #ifndef ZDR_LDS_VERTICES
 #define ZDR_LDS_VERTICES 2
 #endif
@@ -159,6 +162,7 @@ struct BruteAccel {
     ZD static void prepare(const DScene &, int *) {}
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES, kMinWavesFwdEnv = ZDR_MIN_WAVES_ENV;
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD;
+    static constexpr int kPoolExtraBytes = ZDR_POOL_EXTRA_BYTES;
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES;    // scratch records thrash L2 on cbox (1 instead of 2: 16.7 -> 19.0 ms)
     static constexpr bool kFuseRays = false;                 // one walk over the pairs for both rays of a vertex measured no gain
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
@@ -244,6 +248,7 @@ struct BvhAccel {
     static constexpr int kMinWavesFwdEnv = ZDR_MIN_WAVES_BVH;
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // 6 waves per SIMD (<= 80 VGPRs: the path state that is cold during the walk is spilled around it); sweep at ZDR_MIN_WAVES_BVH
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
+    static constexpr int kPoolExtraBytes = 500;               // 16 waves per CU = 8 LDS blocks = 10,240 bytes per wave: 1,536 of stack + 8,664 here
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES_BVH;    // <= 128 VGPRs give 15 waves per CU instead of 11 (109 -> 94 ms on 1 M triangles)
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
     static constexpr bool kFuseRays = true;                  // path_shade hands over both rays of a vertex at once (walk<true, true>)

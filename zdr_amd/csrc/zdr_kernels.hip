@@ -175,6 +175,9 @@ struct ItemBanks {
 // through a pointer to the kernarg segment that is laundered once per trip, so a constant is s_load-ed again where a trip uses it
 // instead of being kept for the whole kernel in an SGPR that is spilled to a VGPR lane (v_readlane / v_writelane / s_nop on the
 // VALU port, 320 reloads in k_path<cmj, brute>).
+#ifndef ZDR_RECORD_POOL
+#define ZDR_RECORD_POOL 1      // backward path kernel: vertex records in a per-wave LDS pool (0: first LV vertices per lane in LDS, the rest in scratch)
+#endif
 #ifndef ZDR_KARG_RELOAD
 #define ZDR_KARG_RELOAD 1
 #endif
@@ -325,9 +328,21 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
 #endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ __attribute__((aligned(16))) float lds_q[ZDR_SCATTER_LDS_FLOATS];   // the queue writes g as one float4
-    constexpr int LV = A::kLdsVertices;                     // vertex records kept in LDS (the others go to scratch)
+    constexpr int LV = A::kLdsVertices;                     // LDS budget for vertex records, in rows of 64 records of 68 bytes
+#if ZDR_RECORD_POOL
+    // The records of all paths of the wave share ONE pool of NS slots (80 bytes + a link each): a lane takes its home slot
+    // (slot == lane) when that is free and otherwise the lowest free one, and gives the slot back when the sweep has read it.
+    // A lane-owned layout [vertex k][lane] kept only the first LV vertices of a path in LDS and sent 17 % of the records
+    // to scratch, whose reads — queued behind the flush's atomics, the same counter — cost 1.4 ms of 13.6.
+    constexpr int NS = (LV * WAVE * 68 + A::kPoolExtraBytes) / 84;
+    static_assert(NS >= 16 && NS <= 128, "the free mask is two 64-bit words");
+    __shared__ float4 lds_pool[5 * NS];                     // [float4 f][slot]
+    __shared__ int lds_link[NS];                            // slot of the path's previous record (255: in scratch, -1: none)
+    __shared__ __attribute__((aligned(16))) unsigned int lds_free[4];   // bit s set: slot s is free (the sweep gives slots back with ds_or)
+#else
     __shared__ float4 lds_rec[LV * 4 * WAVE];
     __shared__ float lds_dlnp[LV * WAVE];
+#endif
     __shared__ uint32_t lds_perm[2 * WAVE];                 // per item bank (see k_path): CMJ seeds, tile origin,
     __shared__ int lds_origin[4];
     __shared__ float lds_leg[2 * 3 * WAVE];                 // and the pixel cotangents / spp
@@ -338,7 +353,19 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
 #endif
     const int lane = threadIdx.x;
     A::prepare(S, lds);
+#if ZDR_RECORD_POOL
+    if (lane < 4) {
+        const unsigned long long all_lo = (NS >= 64) ? ~0ull : ((1ull << (NS & 63)) - 1ull);
+        const unsigned long long all_hi = (NS > 64) ? ((NS >= 128) ? ~0ull : ((1ull << ((NS - 64) & 63)) - 1ull)) : 0ull;
+        const unsigned long long w = (lane < 2) ? all_lo : all_hi;
+        lds_free[lane] = (unsigned int)((lane & 1) ? (w >> 32) : w);
+    }
+    __syncthreads();
+    int last = -1;                                          // where the running path's most recent record lives: slot, 255 = scratch, -1 = none yet
+    int deep_link[ZDR_MAX_RECORDED_DEPTH];
+#else
     const int lds_vertices = (R.rr_depth < LV) ? max(R.rr_depth, 0) : LV;   // LDS records carry no RR fields
+#endif
     Counters cnt;
     ItemBanks ib; ib.logical[0] = ib.logical[1] = -1; ib.inflight[0] = ib.inflight[1] = 0;
     int bank = 1;
@@ -395,6 +422,9 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
             const int bk = took >> 6, px = took & 63;
             le_grad = mk3(lds_leg[(bk * 3 + 0) * WAVE + px], lds_leg[(bk * 3 + 1) * WAVE + px], lds_leg[(bk * 3 + 2) * WAVE + px]);
             nrec = 0;
+#if ZDR_RECORD_POOL
+            last = -1;
+#endif
             alive = true; pix = took;
         }
         if (__ballot(alive) != 0ull) {
@@ -406,17 +436,25 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
             PackedVertex plast;                             // the vertex shaded this trip, as recorded
             plast.a = plast.b = plast.c = plast.d = plast.e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             int sw_k = -1;                                  // next vertex the sweep consumes
+#if ZDR_RECORD_POOL
+            bool want_store = false, mute = false;
+#endif
             SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
             if (alive) {
                 PathVertex pv; float term_plfrac = 0.0f;
                 Hit h;
                 done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
                 plast = pack_vertex(pv, le_grad, R.prb_detached != 0);
+#if !ZDR_RECORD_POOL
                 if (nrec < lds_vertices) plast.e = make_float4(0.0f, 0.0f, 0.0f, plast.e.w);   // LDS records carry no RR fields
+#endif
                 if (!done) { path_continue<A, false>(S, lds, ps, h, cnt); done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac); }
                 // Only a vertex whose path goes on is put away: when the path ends here (52 % of the vertices) the sweep below starts
                 // from plast and nothing would read the record.  (5 LDS or scratch stores per vertex: 16.4 -> 15.5 ms for skipping
                 // the vertices that stop at the shading step alone.)
+#if ZDR_RECORD_POOL
+                want_store = !done && R.debug_no_scatter != 3;   // (ablation 3, no sweep: nothing is kept, so no slot leaks)
+#else
                 if (!done) {
                     if (nrec < lds_vertices) {
                         float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
@@ -424,21 +462,85 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                         lds_dlnp[nrec * WAVE + lane] = plast.e.w;
                     } else if (R.debug_no_scatter != 8) deep[nrec] = plast;   // ablation 8: not written either
                 }
+#endif
                 nrec++;
                 if (done) {
                     alive = false;
+#if ZDR_RECORD_POOL
+                    // a NaN path (prb.py:100: contributes nothing) is swept all the same, muted: the sweep is what returns its slots
+                    if (nrec > 0 && R.debug_no_scatter != 3) {
+                        mute = any_nan(ps.L);
+#else
                     if (!any_nan(ps.L) && nrec > 0) {       // prb.py:100: NaN paths contribute nothing
+#endif
                         sw_k = (R.debug_no_scatter == 3) ? -1 : nrec - 1;   // ablation 3: no sweep at all
                         sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f;
                         sw.tw = R.prb_detached ? 0.0f : term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
                     }
                 }
             }
+#if ZDR_RECORD_POOL
+            // Reconverged: hand out slots, all requests of the trip at once.  Home slot first (slot == lane: conflict-free LDS access);
+            // the lanes whose home is taken — a path's second and later records, or a home another lane borrowed — are ranked, the free
+            // slots are ranked (a lane speaks for slot `lane`, then for slot 64 + lane), and request r takes free slot r: one
+            // ds_permute sends every free slot's number to the lane of its rank, one ds_bpermute lets a request read the number at
+            // its own rank.  Slots above 63 go first so that homes stay free; no slot left: the record goes to scratch.
+            {
+                const unsigned long long req = __ballot(want_store);
+                int slot = -1;
+                if (req != 0ull) {
+                    const uint4 fw = *(const uint4 *)lds_free;                  // same address in every lane: a broadcast read
+                    unsigned long long free_lo = ((unsigned long long)__builtin_amdgcn_readfirstlane(fw.y) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane(fw.x);
+                    unsigned long long free_hi = ((unsigned long long)__builtin_amdgcn_readfirstlane(fw.w) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane(fw.z);
+                    const bool home = want_store && lane < NS && ((free_lo >> lane) & 1ull) != 0ull;
+                    const unsigned long long took = __ballot(home);
+                    free_lo &= ~took;
+                    if (home) slot = lane;
+                    const unsigned long long rest = req & ~took;
+                    if (rest != 0ull && (free_lo | free_hi) != 0ull) {
+                        const int nrest = __popcll(rest);
+                        const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(rest >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rest, 0u));   // rank of this lane's request
+                        const bool mine = want_store && !home;
+                        const int cnt_hi = __popcll(free_hi), cnt_lo = __popcll(free_lo);
+                        // free slots 64 + lane
+                        const bool fh = ((free_hi >> lane) & 1ull) != 0ull;
+                        const int jh = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(free_hi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_hi, 0u));
+                        const int at_hi = __builtin_amdgcn_ds_permute((fh ? jh : cnt_hi + (lane - jh)) << 2, lane);   // lane j < cnt_hi now holds the j-th free slot (minus 64)
+                        const int pick_hi = __builtin_amdgcn_ds_bpermute(r << 2, at_hi);
+                        if (mine && r < cnt_hi) slot = 64 + pick_hi;
+                        free_hi &= ~__ballot(fh && jh < nrest);
+                        // free slots `lane`, for the requests the upper slots did not serve
+                        const int r2 = r - cnt_hi, nrest2 = nrest - cnt_hi;
+                        const bool fl = ((free_lo >> lane) & 1ull) != 0ull;
+                        const int jl = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(free_lo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_lo, 0u));
+                        const int at_lo = __builtin_amdgcn_ds_permute((fl ? jl : cnt_lo + (lane - jl)) << 2, lane);
+                        const int pick_lo = __builtin_amdgcn_ds_bpermute((r2 & 63) << 2, at_lo);
+                        if (mine && r2 >= 0 && r2 < cnt_lo) slot = pick_lo;
+                        free_lo &= ~__ballot(fl && jl < nrest2);
+                    }
+                    if (lane == 0) *(uint4 *)lds_free = make_uint4((unsigned int)free_lo, (unsigned int)(free_lo >> 32), (unsigned int)free_hi, (unsigned int)(free_hi >> 32));
+                }
+                if (want_store) {
+                    if (slot >= 0) {
+                        float4 *r = lds_pool + slot;
+                        r[0] = plast.a; r[NS] = plast.b; r[2 * NS] = plast.c; r[3 * NS] = plast.d; r[4 * NS] = plast.e;
+                        lds_link[slot] = last;
+                        last = slot;
+                    } else {
+                        deep[nrec - 1] = plast; deep_link[nrec - 1] = last;
+                        last = 255;
+                    }
+                }
+            }
+#endif
             ib.inflight[0] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 0));
             ib.inflight[1] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 1));
             // wave-uniform: sweep every finished path to its first vertex.  The sweep starts from the vertex packed this
             // trip (still in registers).
             PackedVertex cur = plast;
+#if ZDR_RECORD_POOL
+            int loc = last;                                 // where the record of the sweep's next step lives
+#endif
 #ifdef ZDR_BWD_STATS   // measurement build (tools/bwd_stats.py): how full are the trips and the sweep iterations
             st_trips++; st_shaded += (unsigned long long)__popcll(__ballot(alive || done));
             st_fin += (unsigned long long)__popcll(__ballot(sw_k >= 0));
@@ -462,6 +564,23 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                 asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), "+v"(guv.x), "+v"(guv.y), "+v"(sw.A.x), "+v"(sw.A.y), "+v"(sw.A.z),
                              "+v"(sw.Lv.x), "+v"(sw.Lv.y), "+v"(sw.Lv.z), "+v"(sw.s), "+v"(sw.Z), "+v"(sw.tw) : : "memory");
                 const bool fetch = swp && sw_k >= 0;
+#if ZDR_RECORD_POOL
+                const bool pooled = fetch && loc != 255;
+                int nloc = -1;
+                if (pooled) {
+                    const float4 *r = lds_pool + loc;
+                    cur.a = r[0]; cur.b = r[NS]; cur.c = r[2 * NS]; cur.d = r[3 * NS]; cur.e = r[4 * NS];
+                    nloc = lds_link[loc];
+                }
+                // LDS first: both kinds of fetch write the same registers (for different lanes), and the second kind waits for the
+                // first to land — an LDS read is back in ~100 cycles, a scratch read in ~500 and behind the flush's atomics
+                asm volatile("" ::: "memory");
+                if (fetch && loc == 255) { cur = deep[sw_k]; nloc = deep_link[sw_k]; }
+                // the slots just read are free again (this wave's LDS operations execute in order: a later write cannot overtake the read)
+                if (pooled) atomicOr(&lds_free[loc >> 5], 1u << (loc & 31));
+                if (fetch) loc = nloc;
+                scatter_push(q, io.cells, swp && !mute && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
+#else
                 if (fetch && sw_k < lds_vertices) {
                     const float4 *r = lds_rec + (sw_k * 4) * WAVE + lane;
                     cur.a = r[0]; cur.b = r[WAVE]; cur.c = r[2 * WAVE]; cur.d = r[3 * WAVE];
@@ -470,8 +589,9 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                 // LDS first: both kinds of fetch write the same registers (for different lanes), and the second kind waits for the
                 // first to land — an LDS read is back in ~100 cycles, a scratch read in ~500
                 asm volatile("" ::: "memory");
-                if (fetch && sw_k >= lds_vertices && R.debug_no_scatter != 7 && R.debug_no_scatter != 8) cur = deep[sw_k];   // ablations 7 / 8: deep records not read back (wrong gradients)
+                if (fetch && sw_k >= lds_vertices && R.debug_no_scatter != 7 && R.debug_no_scatter != 8) cur = deep[sw_k];   // ablations 7 / 8: deep records not read back (wrong gradients; what records out of scratch could save at most)
                 scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
+#endif
             }
         }
 #pragma unroll
@@ -664,6 +784,8 @@ static size_t bvh_dyn_lds(DScene &S, bool backward) {
 }
 // Persistent grid of the path kernels: as many single-wave workgroups as the chip holds at once (never more
 // than there are items).  A workgroup that is not resident at first simply starts later and draws what is left.
+#define ZDR_LDS_BLOCK_BYTES 1280
+#define ZDR_LDS_BLOCKS_PER_CU 128
 template <class K>
 static dim3 persistent_grid(K kernel, size_t dyn, int nitems) {
     int per_cu = 0, dev = 0, cus = 0;
@@ -676,6 +798,14 @@ static dim3 persistent_grid(K kernel, size_t dyn, int nitems) {
         auto it = cache.find(key);
         if (it == cache.end()) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, dyn) != hipSuccess || per_cu < 1) per_cu = 8;
+            // gfx950 hands out its 160 KiB of LDS in 128 blocks of 1,280 bytes and the query above does not round up: with 13,264
+            // bytes per wave it answered 12, 11 were resident, and the twelfth wave of every CU started when the launch was over
+            // (profiles/r3_bwd_records_and_atomics.txt).  A persistent grid must not be larger than what is resident at once.
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, (const void *)kernel) == hipSuccess) {
+                const size_t blocks = (fa.sharedSizeBytes + dyn + ZDR_LDS_BLOCK_BYTES - 1) / ZDR_LDS_BLOCK_BYTES;
+                if (blocks > 0) per_cu = std::max(1, std::min<int>(per_cu, (int)(ZDR_LDS_BLOCKS_PER_CU / blocks)));
+            }
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
             it = cache.emplace(key, std::make_pair(per_cu, cus)).first;
         }

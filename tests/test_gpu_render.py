@@ -231,8 +231,8 @@ def test_tile_masks_cull_nothing_that_can_be_hit(integrator, mat_a, monkeypatch)
     (1, 1, 1, 16, 2),        # one pixel, one sample: a wave with one valid lane and a one-entry FIFO
     (5, 3, 3, 16, 2),        # fewer camera samples than one refill batch
     (24, 16, 32, 1, 2),      # max_depth 1: every path stops after its first vertex
-    (24, 16, 32, 16, 0),     # Russian roulette from the first vertex: no vertex record lives in LDS
-    (24, 16, 32, 16, 16),    # no Russian roulette: paths run to max_depth, 14 records per lane in scratch
+    (24, 16, 32, 16, 0),     # Russian roulette from the first vertex: every record carries its RR fields
+    (24, 16, 32, 16, 16),    # no Russian roulette: paths run to max_depth, up to 15 records per lane — the wave's pool of 106 LDS slots overflows and most records (and their links) go through scratch
     (24, 16, 32, 3, 1),
 ])
 def test_edge_configurations_match_oracle(W, H, spp, max_depth, rr_depth, cbox_oracle, cbox_oracle_fma, mat_a):

@@ -310,13 +310,14 @@ __global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) v
 }
 
 // PRB backward with ONE traversal.  Each trip a live lane shades one vertex of its path (same trip
-// order, primary queue, pixel-free lanes, persistent waves and item banks as k_path) and appends it to its record list: vertices before the first Russian-roulette depth (at
-// most ZDR_LDS_VERTICES of them) live in LDS laid out [slot][float4][lane] (conflict-free ds_*_b128,
-// 4 float4 + one float), deeper ones (25 % of all vertices on cbox) in per-lane scratch (5 float4).
+// order, primary queue, pixel-free lanes, persistent waves and item banks as k_path) and appends it to its record list.  The
+// records (5 float4 + a link to the path's previous one) live in a per-wave LDS POOL, see below; the few that find no slot go to
+// per-lane scratch.  (ZDR_RECORD_POOL=0: the first ZDR_LDS_VERTICES vertices of a path in lane-owned LDS rows
+// [vertex][float4][lane], the others — 17 % of the records on cbox — in scratch.)
 // When a path ends, a short wave-uniform loop sweeps its records last to first and queues the
 // gradients; all queue traffic happens at reconverged points so the whole wave takes part in a flush.
 // Keeping the records out of scratch is what matters: 2.3 KB of scratch per lane thrashed L2 (113 GB of
-// fabric traffic per launch, 13 of 37 ms).
+// fabric traffic per launch, 13 of 37 ms, round 1); the last 17 % cost 1.4 ms of 13.6 (profiles/r3_bwd_records_and_atomics.txt).
 template <int SK, class A, bool ENV>
 __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, RenderCfg R_, SamplerCfg C_, KernelIO io_) {
     ZDR_KARGS_BEGIN

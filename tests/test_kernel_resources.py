@@ -57,11 +57,13 @@ def pick(found, pattern):
     return sel
 
 
-def test_backward_path_kernel_holds_twelve_waves_per_cu_brute_force():
-    """k_path_bwd<*, BruteAccel, *>: LDS is what decides — 10 blocks = 12,800 bytes per wave — and 168 VGPRs."""
+def test_backward_path_kernel_holds_sixteen_waves_per_cu_brute_force():
+    """k_path_bwd<*, BruteAccel, *>: LDS is what decides — 8 blocks = 10,240 bytes per wave (100 pool slots, the scatter queue,
+    the tile origins; neither seeds nor cotangents: accel.h, ZDR_BWD_LEAN_LDS) — and 128 VGPRs."""
     for name, r in pick(kernels(), r"k_path_bwdILi[01]E10BruteAccel").items():
-        assert r["group_segment_fixed_size"] <= 10 * LDS_BLOCK, (name, r)
-        assert waves_per_cu(r["group_segment_fixed_size"], r["vgpr_count"]) >= 12, (name, r)
+        assert r["group_segment_fixed_size"] <= 8 * LDS_BLOCK, (name, r)
+        assert r["vgpr_count"] <= 128, (name, r)
+        assert waves_per_cu(r["group_segment_fixed_size"], r["vgpr_count"]) >= 16, (name, r)
 
 
 def test_backward_path_kernel_holds_sixteen_waves_per_cu_bvh():

@@ -18,16 +18,28 @@
 #ifndef ZDR_MIN_WAVES_BVH
 #define ZDR_MIN_WAVES_BVH 6    // 1 M triangles, forward ms at 1024^2 spp 32 with 4 / 5 / 6 / 7 / 8 waves per SIMD: 32.8 / 31.4 / 30.3 / 31.4 / 39.4
 #endif
+// The backward path kernel's waves per CU are decided by LDS, which gfx950 hands out in 128 blocks of 1,280 bytes per CU:
+// 16 waves = 8 blocks = 10,240 bytes per wave.  ZDR_BWD_LEAN_LDS (default): the kernel keeps neither the CMJ seeds nor the
+// pixel cotangents of its two item banks in LDS (2 KiB: a popped path hashes its seed again and loads its cotangent from the
+// image), which leaves room for a 100-slot record pool in 8 blocks — with 128 VGPRs (no spill since the kernarg reload) 16 waves
+// per CU instead of 12: 12.84 -> 11.37 ms on cbox 512^2 spp 256 (profiles/r3_bwd_records_and_atomics.txt).
+// 0: seeds and cotangents in LDS, 106 slots in 10 blocks, 12 waves per CU.
+#ifndef ZDR_BWD_LEAN_LDS
+#define ZDR_BWD_LEAN_LDS 1
+#endif
 #ifndef ZDR_MIN_WAVES_BWD
-#define ZDR_MIN_WAVES_BWD 3    // LDS holds 12 waves per CU; 4 here = 128 VGPRs with 11 spilled: 14.9 -> 15.6 ms (profiles/r2_bwd_occupancy.txt)
+#define ZDR_MIN_WAVES_BWD (ZDR_BWD_LEAN_LDS ? 4 : 3)
+#endif
+#ifndef ZDR_POOL_SLOTS
+#define ZDR_POOL_SLOTS (ZDR_BWD_LEAN_LDS ? 100 : 106)       // brute force: 10,224 / 12,784 bytes of LDS per wave
+#endif
+#ifndef ZDR_POOL_SLOTS_BVH
+#define ZDR_POOL_SLOTS_BVH (ZDR_BWD_LEAN_LDS ? 80 : 57)     // BVH: + 1,536 bytes of traversal stack, 8 blocks either way
 #endif
 #ifndef ZDR_MIN_WAVES_BWD_BVH
 #define ZDR_MIN_WAVES_BWD_BVH 4
 #endif
 // vertex records of the backward kernel kept in LDS (4.25 KiB per wave each)
-#ifndef ZDR_POOL_EXTRA_BYTES
-#define ZDR_POOL_EXTRA_BYTES 200   // LDS the record pool of the brute-force backward kernel takes beyond the ZDR_LDS_VERTICES rows: gfx950 hands out LDS in 1,280-byte blocks (128 per CU), 12 waves per CU = 10 blocks = 12,800 bytes per wave, and the kernel holds 12,784
-#endif
 #ifndef ZDR_LDS_VERTICES
 #define ZDR_LDS_VERTICES 2
 #endif
@@ -162,7 +174,7 @@ struct BruteAccel {
     ZD static void prepare(const DScene &, int *) {}
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES, kMinWavesFwdEnv = ZDR_MIN_WAVES_ENV;
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD;
-    static constexpr int kPoolExtraBytes = ZDR_POOL_EXTRA_BYTES;
+    static constexpr int kPoolSlots = ZDR_POOL_SLOTS;        // record pool of the backward path kernel (zdr_kernels.hip)
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES;    // scratch records thrash L2 on cbox (1 instead of 2: 16.7 -> 19.0 ms)
     static constexpr bool kFuseRays = false;                 // one walk over the pairs for both rays of a vertex measured no gain
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
@@ -248,7 +260,7 @@ struct BvhAccel {
     static constexpr int kMinWavesFwdEnv = ZDR_MIN_WAVES_BVH;
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // 6 waves per SIMD (<= 80 VGPRs: the path state that is cold during the walk is spilled around it); sweep at ZDR_MIN_WAVES_BVH
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
-    static constexpr int kPoolExtraBytes = 500;               // 16 waves per CU = 8 LDS blocks = 10,240 bytes per wave: 1,536 of stack + 8,664 here
+    static constexpr int kPoolSlots = ZDR_POOL_SLOTS_BVH;
     static constexpr int kLdsVertices = ZDR_LDS_VERTICES_BVH;    // <= 128 VGPRs give 15 waves per CU instead of 11 (109 -> 94 ms on 1 M triangles)
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
     static constexpr bool kFuseRays = true;                  // path_shade hands over both rays of a vertex at once (walk<true, true>)

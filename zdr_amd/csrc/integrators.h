@@ -473,7 +473,7 @@ ZD int primary_pop(const DScene &S, const SamplerCfg &C, bool idle, const uint32
         ps.smp.px = (uint32_t)(lds_origin[bank * 2] + (p & 7)); ps.smp.py = (uint32_t)(lds_origin[bank * 2 + 1] + (p >> 3));
         ps.smp.sample_index = key & 0x01ffffffu;
         ps.smp.dimension = 2;                                                   // pixel_ray drew one 2-D sample
-        ps.smp.permutation_seed = lds_perm[pix];
+        ps.smp.permutation_seed = lds_perm ? lds_perm[pix] : ((SK == 0) ? xxhash32_4(ps.smp.px, ps.smp.py, C.seed, 0u) : 0u);   // (no LDS copy: the pixel's seed is hashed again)
         ps.smp.state = __float_as_uint(b.z);
     }
     q.head += (want < avail) ? want : avail;

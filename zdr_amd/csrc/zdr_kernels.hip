@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
     // (slot == lane) when that is free and otherwise the lowest free one, and gives the slot back when the sweep has read it.
     // A lane-owned layout [vertex k][lane] kept only the first LV vertices of a path in LDS and sent 17 % of the records
     // to scratch, whose reads — queued behind the flush's atomics, the same counter — cost 1.4 ms of 13.6.
-    constexpr int NS = (LV * WAVE * 68 + A::kPoolExtraBytes) / 84;
+    constexpr int NS = A::kPoolSlots;
     static_assert(NS >= 16 && NS <= 128, "the free mask is two 64-bit words");
     __shared__ float4 lds_pool[5 * NS];                     // [float4 f][slot]
     __shared__ int lds_link[NS];                            // slot of the path's previous record (255: in scratch, -1: none)
@@ -344,9 +344,14 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
     __shared__ float4 lds_rec[LV * 4 * WAVE];
     __shared__ float lds_dlnp[LV * WAVE];
 #endif
+#if ZDR_BWD_LEAN_LDS
+    const uint32_t *lds_perm = nullptr;
+    __shared__ int lds_origin[4];
+#else
     __shared__ uint32_t lds_perm[2 * WAVE];                 // per item bank (see k_path): CMJ seeds, tile origin,
     __shared__ int lds_origin[4];
     __shared__ float lds_leg[2 * 3 * WAVE];                 // and the pixel cotangents / spp
+#endif
 #ifdef ZDR_BWD_LDS_PAD                                      // experiment: what fewer waves per CU cost (profiles/r2_bwd_occupancy.txt)
     __shared__ float lds_pad[ZDR_BWD_LDS_PAD];
     if (R.width < 0) lds_pad[threadIdx.x] = 1.0f;
@@ -407,10 +412,14 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                     w = decode_item(R, nxt);
                     perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
                     cam_mask = camera_mask(S, io, w);
+#if ZDR_BWD_LEAN_LDS
+                    if (lane == 0) { lds_origin[bank * 2] = w.x; lds_origin[bank * 2 + 1] = w.y; }
+#else
                     const f3 lg = load_le_grad(C, io, w);
                     lds_perm[bank * WAVE + lane] = perm_seed;
                     if (lane == 0) { lds_origin[bank * 2] = w.x; lds_origin[bank * 2 + 1] = w.y; }
                     lds_leg[(bank * 3 + 0) * WAVE + lane] = lg.x; lds_leg[(bank * 3 + 1) * WAVE + lane] = lg.y; lds_leg[(bank * 3 + 2) * WAVE + lane] = lg.z;
+#endif
                     __syncthreads();
                     next_sample = w.s_begin; s_end = w.s_end;
                 }
@@ -421,7 +430,17 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
         const int took = primary_pop<SK>(S, C, !alive, lds_perm, lds_origin, pq, ps, it);
         if (took >= 0) {
             const int bk = took >> 6, px = took & 63;
+#if ZDR_BWD_LEAN_LDS
+            (void)bk; (void)px;
+            {   // the pixel's cotangent / spp, straight from the image (load_le_grad; a popped path is inside the shard)
+                const float4 gi = io.d_image[ps.smp.px + ps.smp.py * (uint32_t)R.width];
+                const float fs = (float)C.spp;
+                le_grad = mk3(__fdiv_rn(gi.x, fs), __fdiv_rn(gi.y, fs), __fdiv_rn(gi.z, fs));
+                if (any_nan(le_grad)) le_grad = mk3(0.0f);
+            }
+#else
             le_grad = mk3(lds_leg[(bk * 3 + 0) * WAVE + px], lds_leg[(bk * 3 + 1) * WAVE + px], lds_leg[(bk * 3 + 2) * WAVE + px]);
+#endif
             nrec = 0;
 #if ZDR_RECORD_POOL
             last = -1;

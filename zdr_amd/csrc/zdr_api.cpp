@@ -809,7 +809,7 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     const long all_tiles = (long)R.tiles_x * R.tiles_y;
     R.ntiles = (int32_t)(all_tiles > R.shard_index ? (all_tiles - R.shard_index + R.shard_count - 1) / R.shard_count : 0);
     long tiles = R.ntiles;
-    long target_waves = 65536;            // work items (tile x sample chunk) the persistent waves draw; cbox 512^2 spp 256: 16384 11.3/18.5 ms, 32768 10.7/17.7, 65536 10.25/17.2, 131072 10.2/17.1
+    long target_waves = (backward && p->integrator == ZDR_PATH) ? 131072 : 65536;   // (path backward, 4,096 resident waves since the kernel holds 16 per CU: 131072 11.22 ms, 65536 11.40; forward: the finer split is no faster) work items (tile x sample chunk) the persistent waves draw; cbox 512^2 spp 256: 16384 11.3/18.5 ms, 32768 10.7/17.7, 65536 10.25/17.2, 131072 10.2/17.1
     if (const char *e = getenv("ZDR_TARGET_WAVES")) target_waves = std::max(1L, atol(e));
     uint32_t min_chunk = 8;               // = one refill batch; cbox 512^2 forward / backward ms with 16 / 8 / 4: spp 16 1.10 / 0.99 / 1.06, 1.63 / 1.41 / 1.41; spp 64 2.90 / 2.86 / 2.92, 4.35 / 4.12 / 4.16; spp 256 unchanged
     if (const char *e = getenv("ZDR_MIN_CHUNK")) min_chunk = (uint32_t)std::max(1L, atol(e));

@@ -109,7 +109,7 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     float4 mat_grad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     f3 radiance = mk3(0.0f);
     float u_pick = sampler_next<SK>(C, smp);
-    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, smp); }, [&]() { return sampler_next2<SK>(C, smp); });
+    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, smp); }, [&]() { return sampler_next2<SK>(C, smp); });   // (the batched draw of sampler.h costs this kernel more in spills — 128 VGPRs — than it saves)
     COUNT(C_SHADOW);
     bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
     Onb onb = make_onb(it.ns);
@@ -240,7 +240,7 @@ ZD bool path_arrive(const DScene &S, PathState &ps, const Hit &h, Interaction &i
 //                        continuation ray as soon as its shadow ray has ended; no shadow ray at all when the light
 //                        sample carries nothing), then the NEE terms are added if the shadow ray came through.
 // BWD: fills pv, the record of this vertex.
-struct ShadeCtx { f3 diffuse; float roughness; Onb onb; f3 wo, wil; LightSample light; };
+struct ShadeCtx { f3 diffuse; float roughness; Onb onb; f3 wo, wil; LightSample light; float u_lobe; f2 u_dir; bool pre; };   // pre: the BSDF sample's numbers were drawn with the light's (cmj_vertex_samples)
 // The light sample's contribution AS IF it were unoccluded (prb.py:60-66); applied once the shadow ray is known to be free.
 struct NeeTerms { f3 dL, bW, fLW, neeM; float cL, dfLdr; };
 
@@ -258,8 +258,16 @@ ZD ShadeCtx shade_ctx(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     x.onb = make_onb(it.ns);
     x.wo = to_local(x.onb, -ps.d);
     // next-event estimation: the light sample (prb.py:57-58)
-    float u_pick = sampler_next<SK>(C, ps.smp);
-    x.light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
+    x.pre = (SK == 0) && !ENV && cmj_can_batch(C);               // wave-uniform
+    x.u_lobe = 0.0f; x.u_dir.x = 0.0f; x.u_dir.y = 0.0f;
+    if (x.pre) {                                                 // all seven numbers of the vertex at once, two permutations per register (sampler.h)
+        const VertexSamples v = cmj_vertex_samples(C, ps.smp);
+        x.u_lobe = v.u_lobe; x.u_dir = v.u_dir;
+        x.light = sample_light<ENV>(S, it.p, v.u_pick, [&]() { return v.u_prim; }, [&]() { return v.u_pt; });
+    } else {
+        float u_pick = sampler_next<SK>(C, ps.smp);
+        x.light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, ps.smp); }, [&]() { return sampler_next2<SK>(C, ps.smp); });
+    }
     x.wil = to_local(x.onb, x.light.wi);
     return x;
 }
@@ -292,8 +300,8 @@ ZD void nee_apply(PathState &ps, PathVertex &pv, const NeeTerms &n) {
 // BSDF sampling and Russian roulette (prb.py:69-87); true = the path stops here, else (ps.o, ps.d) is the continuation ray
 template <int SK, bool BWD>
 ZD bool sample_bsdf(const RenderCfg &R, const SamplerCfg &C, const ShadeCtx &x, PathState &ps, const Interaction &it, PathVertex &pv) {
-    float u_lobe = sampler_next<SK>(C, ps.smp);
-    f2 u_dir = sampler_next2<SK>(C, ps.smp);
+    float u_lobe = x.u_lobe; f2 u_dir = x.u_dir;
+    if (!x.pre) { u_lobe = sampler_next<SK>(C, ps.smp); u_dir = sampler_next2<SK>(C, ps.smp); }
     f3 wi_local = ggx_sample(x.wo, x.roughness, u_lobe, u_dir);
     GgxTerms g = ggx_terms(x.wo, wi_local, x.roughness);
     ps.pdf_bsdf = ggx_pdf_from(g, x.wo, wi_local);

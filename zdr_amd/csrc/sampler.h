@@ -153,3 +153,69 @@ ZD f2 sampler_next2(const SamplerCfg &c, Sampler &s) {
     }
     return u;
 }
+
+// ------------------------------------------------------------------ the seven CMJ numbers of a path vertex, two hashes per register
+// A path vertex draws, in this order, next() (light pick), next() (triangle pick), next2() (point on the light), next() (lobe),
+// next2() (direction): nine Kensler permutations — five of the sample index over [0, spp), four of a stratum coordinate over
+// [0, res) — each 9 multiplies and ~20 logic operations on the VALU-bound kernels' critical resource.  The permutation only ever
+// looks at the bits of its state below the mask's top bit (multiplication, xor and `(i & w) >> k` never carry information downwards
+// past that), so for w <= 0xffff the state fits 16 bits and TWO permutations run in the halves of one register: v_pk_mul_lo_u16,
+// v_pk_lshrrev_b16, v_pk_add_u16 and plain logic.  Same values bit for bit (tests/test_gpu_paths.py compares every vertex of
+// every path with the oracle); five passes instead of nine.  Valid for the CMJ sampler with power-of-two spp and strata grid
+// (every BASELINE configuration); anything else takes the calls one by one.
+typedef unsigned short zdr_us2 __attribute__((ext_vector_type(2)));
+ZD uint32_t pk_mul16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (zdr_us2)(__builtin_bit_cast(zdr_us2, a) * __builtin_bit_cast(zdr_us2, b))); }
+ZD uint32_t pk_add16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (zdr_us2)(__builtin_bit_cast(zdr_us2, a) + __builtin_bit_cast(zdr_us2, b))); }
+template <int K> ZD uint32_t pk_shr16(uint32_t a) { return __builtin_bit_cast(uint32_t, (zdr_us2)(__builtin_bit_cast(zdr_us2, a) >> (unsigned short)K)); }
+
+// permutation_element(i.lo, w.lo + 1, w.lo, pa) in the low half, (i.hi, w.hi + 1, w.hi, pb) in the high half; l == w + 1 in both
+ZD uint32_t permutation_element2(uint32_t i, uint32_t w, uint32_t pa, uint32_t pb, bool small_w) {
+    const uint32_t P0 = __builtin_amdgcn_perm(pb, pa, 0x05040100u);      // {pa & 0xffff, pb & 0xffff}
+    const uint32_t P16 = __builtin_amdgcn_perm(pb, pa, 0x07060302u);     // {pa >> 16, pb >> 16}
+    const uint32_t P8 = __builtin_amdgcn_perm(pb, pa, 0x06050201u);      // {(pa >> 8) & 0xffff, (pb >> 8) & 0xffff}
+    i ^= P0; i = pk_mul16(i, 0x893d893du); i ^= P16; i ^= pk_shr16<4>(i & w); i ^= P8;
+    i = pk_mul16(i, 0xeb3feb3fu); i ^= pk_shr16<7>(P16); i ^= pk_shr16<1>(i & w); i = pk_mul16(i, pk_shr16<11>(P16) | 0x00010001u);
+    if (small_w) i = pk_mul16(i, ((0x6935fa69u * 0x74dcb303u) & 0xffffu) * 0x00010001u);
+    else { i = pk_mul16(i, 0xfa69fa69u); i ^= pk_shr16<11>(i & w); i = pk_mul16(i, 0xb303b303u); }
+    i ^= pk_shr16<2>(i & w);
+    i = pk_mul16(i, 0x1cc31cc3u); i ^= pk_shr16<2>(i & w); i = pk_mul16(i, 0xa3dfa3dfu); i &= w; i ^= pk_shr16<5>(i);
+    return pk_add16(i, P0) & w;
+}
+
+struct VertexSamples { float u_pick, u_prim; f2 u_pt; float u_lobe; f2 u_dir; };
+ZD bool cmj_can_batch(const SamplerCfg &c) {                        // wave-uniform
+    return c.spp_pow2 && c.res_pow2 && c.spp <= 65536u && c.w == c.spp - 1u && c.resw_x == c.res_x - 1u && c.resw_y == c.res_y - 1u;
+}
+ZD VertexSamples cmj_vertex_samples(const SamplerCfg &c, Sampler &s) {
+    const uint32_t M = 0x70ffffffu;
+    const uint32_t ps = s.permutation_seed + s.dimension;
+    const uint32_t W = c.w | (c.w << 16), I = s.sample_index | (s.sample_index << 16);
+    const bool small_w = c.w < 2048u;
+    // the five permutations of the sample index (corrmj.py:95-102 and 105-108), dimensions +0 +1 +2 +4 +5
+    const uint32_t h01 = permutation_element2(I, W, (ps * 0x45fbe943u) & M, ((ps + 1u) * 0x45fbe943u) & M, small_w);
+    const uint32_t h23 = permutation_element2(I, W, ((ps + 2u) * 0x51633e2du) & M, ((ps + 4u) * 0x45fbe943u) & M, small_w);
+    const uint32_t i_dir = permutation_element(s.sample_index, c.spp, c.w, ((ps + 5u) * 0x51633e2du) & M);
+    const uint32_t i_pick = h01 & 0xffffu, i_prim = h01 >> 16, i_pt = h23 & 0xffffu, i_lobe = h23 >> 16;
+    // the strata of the two 2-D draws (corrmj.py:109-112): x and y permuted in one pass each
+    const uint32_t WR = c.resw_x | (c.resw_y << 16);
+    const bool small_r = (c.resw_x | c.resw_y) < 2048u;
+    const uint32_t x_pt = i_pt & (c.res_x - 1u), y_pt = i_pt >> c.res_x_shift, x_dir = i_dir & (c.res_x - 1u), y_dir = i_dir >> c.res_x_shift;
+    const uint32_t s_pt = permutation_element2(x_pt | (y_pt << 16), WR, ((ps + 2u) * 0x68bc21ebu) & M, ((ps + 2u) * 0x02e5be93u) & M, small_r);
+    const uint32_t s_dir = permutation_element2(x_dir | (y_dir << 16), WR, ((ps + 5u) * 0x68bc21ebu) & M, ((ps + 5u) * 0x02e5be93u) & M, small_r);
+    // the jitters, in call order (corrmj.py:88-92)
+    const float d_pick = next_lcg(s), d_prim = next_lcg(s), dx_pt = next_lcg(s), dy_pt = next_lcg(s), d_lobe = next_lcg(s), dx_dir = next_lcg(s), dy_dir = next_lcg(s);
+    VertexSamples v;
+    v.u_pick = strat(c, i_pick, d_pick); v.u_prim = strat(c, i_prim, d_prim); v.u_lobe = strat(c, i_lobe, d_lobe);
+    {
+        const float ax = (float)(s_pt >> 16) + dx_pt, ay = (float)(s_pt & 0xffffu) + dy_pt;       // (sy + dx, sx + dy)
+        v.u_pt.x = clampf(((float)x_pt + ax * c.inv_res_y) * c.inv_res_x, 0.0f, ZDR_ONE_MINUS_EPS);
+        v.u_pt.y = clampf(((float)y_pt + ay * c.inv_res_x) * c.inv_res_y, 0.0f, ZDR_ONE_MINUS_EPS);
+    }
+    {
+        const float ax = (float)(s_dir >> 16) + dx_dir, ay = (float)(s_dir & 0xffffu) + dy_dir;
+        v.u_dir.x = clampf(((float)x_dir + ax * c.inv_res_y) * c.inv_res_x, 0.0f, ZDR_ONE_MINUS_EPS);
+        v.u_dir.y = clampf(((float)y_dir + ay * c.inv_res_x) * c.inv_res_y, 0.0f, ZDR_ONE_MINUS_EPS);
+    }
+    s.dimension += 7;
+    return v;
+}

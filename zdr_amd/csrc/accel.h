@@ -31,10 +31,10 @@
 #define ZDR_MIN_WAVES_BWD (ZDR_BWD_LEAN_LDS ? 4 : 3)
 #endif
 #ifndef ZDR_POOL_SLOTS
-#define ZDR_POOL_SLOTS (ZDR_BWD_LEAN_LDS ? 100 : 106)       // brute force: 10,224 / 12,784 bytes of LDS per wave
+#define ZDR_POOL_SLOTS (ZDR_BWD_LEAN_LDS ? 103 : 106)       // brute force: 10,176 bytes of LDS per wave (103 x 81 + the scatter queue + 48) / 12 waves per CU
 #endif
 #ifndef ZDR_POOL_SLOTS_BVH
-#define ZDR_POOL_SLOTS_BVH (ZDR_BWD_LEAN_LDS ? 80 : 57)     // BVH: + 1,536 bytes of traversal stack, 8 blocks either way
+#define ZDR_POOL_SLOTS_BVH (ZDR_BWD_LEAN_LDS ? 84 : 57)     // BVH: + 1,536 bytes of traversal stack, 8 blocks either way
 #endif
 #ifndef ZDR_MIN_WAVES_BWD_BVH
 #define ZDR_MIN_WAVES_BWD_BVH 4

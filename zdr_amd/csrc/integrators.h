@@ -240,7 +240,7 @@ ZD bool path_arrive(const DScene &S, PathState &ps, const Hit &h, Interaction &i
 //                        continuation ray as soon as its shadow ray has ended; no shadow ray at all when the light
 //                        sample carries nothing), then the NEE terms are added if the shadow ray came through.
 // BWD: fills pv, the record of this vertex.
-struct ShadeCtx { f3 diffuse; float roughness; Onb onb; f3 wo, wil; LightSample light; float u_lobe; f2 u_dir; bool pre; };   // pre: the BSDF sample's numbers were drawn with the light's (cmj_vertex_samples)
+struct ShadeCtx { f3 diffuse; float roughness; Onb onb; f3 wo, wil; LightSample light; float u_lobe; f2 u_dir; uint32_t i_rr; bool pre; };   // pre: the BSDF sample's numbers were drawn with the light's (cmj_vertex_samples)
 // The light sample's contribution AS IF it were unoccluded (prb.py:60-66); applied once the shadow ray is known to be free.
 struct NeeTerms { f3 dL, bW, fLW, neeM; float cL, dfLdr; };
 
@@ -259,10 +259,10 @@ ZD ShadeCtx shade_ctx(const DScene &S, const RenderCfg &R, const SamplerCfg &C, 
     x.wo = to_local(x.onb, -ps.d);
     // next-event estimation: the light sample (prb.py:57-58)
     x.pre = (SK == 0) && !ENV && cmj_can_batch(C);               // wave-uniform
-    x.u_lobe = 0.0f; x.u_dir.x = 0.0f; x.u_dir.y = 0.0f;
+    x.u_lobe = 0.0f; x.u_dir.x = 0.0f; x.u_dir.y = 0.0f; x.i_rr = 0u;
     if (x.pre) {                                                 // all seven numbers of the vertex at once, two permutations per register (sampler.h)
         const VertexSamples v = cmj_vertex_samples(C, ps.smp);
-        x.u_lobe = v.u_lobe; x.u_dir = v.u_dir;
+        x.u_lobe = v.u_lobe; x.u_dir = v.u_dir; x.i_rr = v.i_rr;
         x.light = sample_light<ENV>(S, it.p, v.u_pick, [&]() { return v.u_prim; }, [&]() { return v.u_pt; });
     } else {
         float u_pick = sampler_next<SK>(C, ps.smp);
@@ -320,7 +320,7 @@ ZD bool sample_bsdf(const RenderCfg &R, const SamplerCfg &C, const ShadeCtx &x, 
             if (l == 0.0f) stop = true;
             else {
                 q = fmaxf(l, 0.05f);
-                float r = sampler_next<SK>(C, ps.smp);
+                float r = x.pre ? cmj_next_with_index(C, ps.smp, x.i_rr) : sampler_next<SK>(C, ps.smp);
                 if (r >= q) stop = true;
                 else { ps.beta = ps.beta * rcp(q); rr_kind = (l >= 1.0f) ? 2 : ((l >= 0.05f) ? 1 : 0); }
             }

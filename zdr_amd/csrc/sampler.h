@@ -161,7 +161,7 @@ ZD f2 sampler_next2(const SamplerCfg &c, Sampler &s) {
 // looks at the bits of its state below the mask's top bit (multiplication, xor and `(i & w) >> k` never carry information downwards
 // past that), so for w <= 0xffff the state fits 16 bits and TWO permutations run in the halves of one register: v_pk_mul_lo_u16,
 // v_pk_lshrrev_b16, v_pk_add_u16 and plain logic.  Same values bit for bit (tests/test_gpu_paths.py compares every vertex of
-// every path with the oracle); five passes instead of nine.  Valid for the CMJ sampler with power-of-two spp and strata grid
+// every path with the oracle); five passes instead of nine — ten with the Russian-roulette draw, whose permutation shares the fifth.  Valid for the CMJ sampler with power-of-two spp and strata grid
 // (every BASELINE configuration); anything else takes the calls one by one.
 typedef unsigned short zdr_us2 __attribute__((ext_vector_type(2)));
 ZD uint32_t pk_mul16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (zdr_us2)(__builtin_bit_cast(zdr_us2, a) * __builtin_bit_cast(zdr_us2, b))); }
@@ -182,7 +182,7 @@ ZD uint32_t permutation_element2(uint32_t i, uint32_t w, uint32_t pa, uint32_t p
     return pk_add16(i, P0) & w;
 }
 
-struct VertexSamples { float u_pick, u_prim; f2 u_pt; float u_lobe; f2 u_dir; };
+struct VertexSamples { float u_pick, u_prim; f2 u_pt; float u_lobe; f2 u_dir; uint32_t i_rr; };   // i_rr: the permuted index of the NEXT 1-D draw (Russian roulette), should the vertex make it
 ZD bool cmj_can_batch(const SamplerCfg &c) {                        // wave-uniform
     return c.spp_pow2 && c.res_pow2 && c.spp <= 65536u && c.w == c.spp - 1u && c.resw_x == c.res_x - 1u && c.resw_y == c.res_y - 1u;
 }
@@ -194,8 +194,8 @@ ZD VertexSamples cmj_vertex_samples(const SamplerCfg &c, Sampler &s) {
     // the five permutations of the sample index (corrmj.py:95-102 and 105-108), dimensions +0 +1 +2 +4 +5
     const uint32_t h01 = permutation_element2(I, W, (ps * 0x45fbe943u) & M, ((ps + 1u) * 0x45fbe943u) & M, small_w);
     const uint32_t h23 = permutation_element2(I, W, ((ps + 2u) * 0x51633e2du) & M, ((ps + 4u) * 0x45fbe943u) & M, small_w);
-    const uint32_t i_dir = permutation_element(s.sample_index, c.spp, c.w, ((ps + 5u) * 0x51633e2du) & M);
-    const uint32_t i_pick = h01 & 0xffffu, i_prim = h01 >> 16, i_pt = h23 & 0xffffu, i_lobe = h23 >> 16;
+    const uint32_t h45 = permutation_element2(I, W, ((ps + 5u) * 0x51633e2du) & M, ((ps + 7u) * 0x45fbe943u) & M, small_w);   // the fifth goes with the roulette's, which follows at dimension +7 if it is drawn at all
+    const uint32_t i_pick = h01 & 0xffffu, i_prim = h01 >> 16, i_pt = h23 & 0xffffu, i_lobe = h23 >> 16, i_dir = h45 & 0xffffu;
     // the strata of the two 2-D draws (corrmj.py:109-112): x and y permuted in one pass each
     const uint32_t WR = c.resw_x | (c.resw_y << 16);
     const bool small_r = (c.resw_x | c.resw_y) < 2048u;
@@ -216,6 +216,13 @@ ZD VertexSamples cmj_vertex_samples(const SamplerCfg &c, Sampler &s) {
         v.u_dir.x = clampf(((float)x_dir + ax * c.inv_res_y) * c.inv_res_x, 0.0f, ZDR_ONE_MINUS_EPS);
         v.u_dir.y = clampf(((float)y_dir + ay * c.inv_res_x) * c.inv_res_y, 0.0f, ZDR_ONE_MINUS_EPS);
     }
+    v.i_rr = h45 >> 16;
     s.dimension += 7;
     return v;
+}
+// sampler_next<cmj> with the permutation already done (cmj_vertex_samples' i_rr): corrmj.py:95-102
+ZD float cmj_next_with_index(const SamplerCfg &c, Sampler &s, uint32_t index) {
+    const float delta = next_lcg(s);
+    s.dimension += 1;
+    return strat(c, index, delta);
 }

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
     constexpr int NS = A::kPoolSlots;
     static_assert(NS >= 16 && NS <= 128, "the free mask is two 64-bit words");
     __shared__ float4 lds_pool[5 * NS];                     // [float4 f][slot]
-    __shared__ int lds_link[NS];                            // slot of the path's previous record (255: in scratch, -1: none)
+    __shared__ unsigned char lds_link[NS];                  // slot of the path's previous record (255: in scratch; a path's first record links to nothing and its link is never followed).  One byte: three more slots fit
     __shared__ __attribute__((aligned(16))) unsigned int lds_free[4];   // bit s set: slot s is free (the sweep gives slots back with ds_or)
 #else
     __shared__ float4 lds_rec[LV * 4 * WAVE];
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                     if (slot >= 0) {
                         float4 *r = lds_pool + slot;
                         r[0] = plast.a; r[NS] = plast.b; r[2 * NS] = plast.c; r[3 * NS] = plast.d; r[4 * NS] = plast.e;
-                        lds_link[slot] = last;
+                        lds_link[slot] = (unsigned char)last;
                         last = slot;
                     } else {
                         deep[nrec - 1] = plast; deep_link[nrec - 1] = last;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                 if (pooled) {
                     const float4 *r = lds_pool + loc;
                     cur.a = r[0]; cur.b = r[NS]; cur.c = r[2 * NS]; cur.d = r[3 * NS]; cur.e = r[4 * NS];
-                    nloc = lds_link[loc];
+                    nloc = (int)lds_link[loc];
                 }
                 // LDS first: both kinds of fetch write the same registers (for different lanes), and the second kind waits for the
                 // first to land — an LDS read is back in ~100 cycles, a scratch read in ~500 and behind the flush's atomics

@@ -77,6 +77,22 @@ def test_cbox_paths(accel, material, oracles):
     check(cons, st, fl, what, tight=(material == "A"))
 
 
+@pytest.mark.parametrize("W,H,spp", [
+    (4, 4, 4096),        # w = 4095: the permutations' (i & w) >> 11 term is live — the packed pass takes its general branch
+    (2, 2, 65536),       # w = 0xffff: the largest sample count whose permutation state fits the 16-bit halves
+    (2, 1, 131072),      # beyond it: every draw goes through the one-by-one sampler again
+    (8, 4, 48),          # not a power of two: the cycle-walking permutation and exact divisions, one by one
+])
+def test_paths_at_sample_counts_on_the_samplers_other_branches(W, H, spp, oracles):
+    """cmj_vertex_samples (sampler.h) draws a vertex's numbers with two permutations per register when spp and the strata grid are
+    powers of two and spp <= 65536; these renders sit on and beyond the edges of that, path by path against the oracle."""
+    scene = make_scene("path")
+    mat = cbox_material_np()
+    what = f"cbox material A, {W}x{H} spp {spp}"
+    cons, st, fl = run_case(scene, oracles[0], oracles[1], mat, W, H, spp, 31, what)
+    check(cons, st, fl, what, tight=True)
+
+
 def test_box_filter_and_roulette_from_the_first_vertex(oracles):
     scene = make_scene("path")
     scene.use_tent_filter = False

@@ -67,10 +67,10 @@ def test_backward_path_kernel_holds_sixteen_waves_per_cu_brute_force():
 
 
 def test_backward_path_kernel_holds_sixteen_waves_per_cu_bvh():
-    """k_path_bwd<*, BvhAccel, *>: 8 blocks = 10,240 bytes per wave, 1,536 of which are the traversal stack the launcher adds
-    (ZDR_BVH_LDS_STACK_BWD = 6 entries x 64 lanes x 4 bytes), and 128 VGPRs."""
+    """k_path_bwd<*, BvhAccel, *>: 8 blocks = 10,240 bytes per wave, 2,560 of which are the traversal stack the launcher adds
+    (ZDR_BVH_LDS_STACK_BWD = 10 entries x 64 lanes x 4 bytes), and 128 VGPRs."""
     for name, r in pick(kernels(), r"k_path_bwdILi[01]E8BvhAccel").items():
-        assert r["group_segment_fixed_size"] + 6 * 256 <= 8 * LDS_BLOCK, (name, r)
+        assert r["group_segment_fixed_size"] + 10 * 256 <= 8 * LDS_BLOCK, (name, r)
         assert r["vgpr_count"] <= 128, (name, r)
 
 

@@ -34,7 +34,7 @@
 #define ZDR_POOL_SLOTS (ZDR_BWD_LEAN_LDS ? 103 : 106)       // brute force: 10,176 bytes of LDS per wave (103 x 81 + the scatter queue + 48) / 12 waves per CU
 #endif
 #ifndef ZDR_POOL_SLOTS_BVH
-#define ZDR_POOL_SLOTS_BVH (ZDR_BWD_LEAN_LDS ? 84 : 57)     // BVH: + 1,536 bytes of traversal stack, 8 blocks either way
+#define ZDR_POOL_SLOTS_BVH (ZDR_BWD_LEAN_LDS ? 72 : 57)     // BVH: + the traversal stack (ZDR_BVH_LDS_STACK_BWD entries x 256 bytes), 8 blocks either way
 #endif
 #ifndef ZDR_MIN_WAVES_BWD_BVH
 #define ZDR_MIN_WAVES_BWD_BVH 4

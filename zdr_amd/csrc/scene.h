@@ -16,7 +16,7 @@
 #define ZDR_BVH_LDS_STACK 12
 #endif
 #ifndef ZDR_BVH_LDS_STACK_BWD
-#define ZDR_BVH_LDS_STACK_BWD 6
+#define ZDR_BVH_LDS_STACK_BWD 10   // (6 until the backward kernel's records moved into a pool: 1 M triangles, 1024^2 spp 32, stack entries / pool slots in the same 8 LDS blocks: 4 / 90 35.2 ms, 6 / 84 34.0, 10 / 72 32.8, 12 / 65 32.8, 14 / 59 32.8)
 #endif
 // The top of the tree in LDS (a per-wave copy of nodes 0 .. K-1 behind the stack; the builder numbers the top of the tree breadth-first):
 // a divergent 64-byte fetch costs the vector-memory path ~3 cycles per ACTIVE lane from L2 against 20-26 cycles per WAVE from LDS

@@ -36,7 +36,7 @@ enum { ZDR_COLLOCATED = 0, ZDR_DIRECT = 1, ZDR_PATH = 2, ZDR_UVGRAD = 3 };
 enum { ZDR_SAMPLER_CMJ = 0, ZDR_SAMPLER_PMJ02BN = 1 };
 /* acceleration structure used for LuisaCompute's Accel (render.py:74,109,127) */
 enum { ZDR_ACCEL_AUTO = 0, ZDR_ACCEL_BRUTE = 1, ZDR_ACCEL_BVH = 2 };
-enum { ZDR_PRB_EXPECTATION = 0, ZDR_PRB_DETACHED = 1 };
+enum { ZDR_PRB_EXPECTATION = 0, ZDR_PRB_DETACHED = 1, ZDR_PRB_LITERAL = 2 };
 
 typedef struct zdr_scene zdr_scene;
 
@@ -72,7 +72,11 @@ typedef struct {
      * Russian roulette without an upper clamp (prb.py:83) makes the expectation depend on the roulette probabilities and
      * on the MIS weights, and this form differentiates through them.  ZDR_PRB_DETACHED (1): every roulette factor and MIS
      * weight held constant, which is what the reference's autodiff blocks compute (prb.py:138-146, 157-163, with the
-     * corrected BSDF weight of SURVEY App. B-3). */
+     * corrected BSDF weight of SURVEY App. B-3).  ZDR_PRB_LITERAL (2): as DETACHED but with the BSDF-sample adjoint seeded
+     * exactly as prb.py:157-163 writes it, backward(bsdf, beta / pdf_bsdf * Le * le_grad) with Le the remaining path
+     * radiance — which already contains beta * bsdf / pdf, so this is NOT the derivative of the forward (19 % off finite
+     * differences, tests/test_oracle_render.py); it exists so that the one output the reference defines and the other two
+     * modes cannot produce is available for comparison. */
     int32_t prb_mode;
 } zdr_render_params;
 
@@ -162,6 +166,16 @@ int zdr_trace_any(zdr_scene *scene, const float *rays, uint32_t n, int32_t *occl
  * (SURVEY App. A.8); unused slots are 0. */
 int zdr_sampler_dump(zdr_scene *scene, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries,
                      uint32_t n, int32_t nvert, int32_t rr_depth, float *out, void *stream);
+
+/* The same draws, produced THE WAY THE PATH KERNELS PRODUCE THEM: on every BASELINE configuration (CMJ, power-of-two spp
+ * <= 65536 and strata grid) the path kernels do not call next() / next2f() one by one (corrmj.py:95-117) but draw a
+ * vertex's seven numbers at once with two Kensler permutations per register (csrc/sampler.h, cmj_vertex_samples) and the
+ * Russian-roulette number from an index permuted alongside (cmj_next_with_index).  This entry point runs exactly that code
+ * — and the one-by-one calls where the kernels fall back to them — so that "sample indices bit-exact" is asserted on the
+ * instructions the renders execute.  Same arguments and output layout as zdr_sampler_dump; *batched (HOST, may be NULL)
+ * receives 1 when the packed route was taken, 0 for the fallback. */
+int zdr_vertex_sampler_dump(zdr_scene *scene, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries,
+                            uint32_t n, int32_t nvert, int32_t rr_depth, float *out, int32_t *batched, void *stream);
 
 /* Per-path traces of the path integrator, for comparing the kernels with the oracle PATH BY PATH (glossy materials
  * amplify last-ulp differences, so whole-image statistics alone cannot tell a flipped branch from wrong arithmetic).

@@ -474,10 +474,32 @@ def test_detached_adjoint_mode_matches_oracle(accel, cbox_oracle, cbox_oracle_fm
     scene.render_backward(torch.from_numpy(cot).cuda(), g2, m, (W, W), spp, seed)
     rough = (g2[..., 3] - g[..., 3]).abs().sum() / g2[..., 3].abs().sum()
     assert rough > 0.01                                           # the roughness channel is where the two forms differ
-    from zdr_amd._native import ZdrError
-    scene.prb_mode = "literal"
+    scene.prb_mode = "no such mode"
     with pytest.raises(KeyError):
         scene.render_backward(torch.from_numpy(cot).cuda(), g2, m, (W, W), spp, seed)
+
+
+@pytest.mark.parametrize("accel", ["brute", "bvh"])
+def test_literal_adjoint_mode_matches_oracle(accel, cbox_oracle, cbox_oracle_fma, mat_b):
+    """scene.prb_mode = "literal": the BSDF-sample adjoint seeded as /root/reference/prb.py:157-163 writes it —
+    backward(bsdf, beta / pdf_bsdf * Le * le_grad) with Le the REMAINING path radiance — against the oracle's ZDRO_PRB_LITERAL.
+    Not the derivative of the forward (tests/test_oracle_render.py::test_prb_literal_weight_is_not_the_derivative: 19 % off finite
+    differences); the mode exists because it is the one output the reference defines that the other two cannot produce."""
+    scene = make_scene("path", accel=accel)
+    scene.prb_mode = "literal"
+    W, spp, seed = 64, 16, 33
+    cot = np.random.default_rng(9).uniform(0.5, 1.5, (W, W, 4)).astype(np.float32)
+    m = torch.from_numpy(mat_b).cuda()
+    g = torch.zeros_like(m)
+    scene.render_backward(torch.from_numpy(cot).cuda(), g, m, (W, W), spp, seed)
+    p = oracle_params(scene, W, W, spp, seed + 1, mat_b.shape[:2], prb_mode=oracle.PRB_LITERAL)
+    ref = cbox_oracle.render_backward(p, cot, mat_b)
+    assert_grad_parity(g.cpu().numpy(), ref, f"literal adjoint / {accel}", floor=cbox_oracle_fma.render_backward(p, cot, mat_b),
+                       flips=Flips(scene, cbox_oracle, cbox_oracle_fma, mat_b, (W, W), spp, seed + 1, cot=cot, what=f"literal adjoint / {accel}", prb_mode=oracle.PRB_LITERAL))
+    scene.prb_mode = "detached"
+    g2 = torch.zeros_like(m)
+    scene.render_backward(torch.from_numpy(cot).cuda(), g2, m, (W, W), spp, seed)
+    assert ((g2 - g).abs().sum() / g2.abs().sum()) > 0.01        # and it is a different gradient from the detached form's
 
 
 def test_rccl_single_rank_exchange(mat_a):

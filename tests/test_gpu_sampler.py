@@ -22,6 +22,33 @@ def test_cmj_draws_bit_exact(spp):
             assert (got[k, :exp.shape[0]].view(np.uint32) == exp.view(np.uint32)).all(), (spp, seed, q[k])
 
 
+# The draws AS THE PATH KERNELS MAKE THEM (zdr_vertex_sampler_dump): on every BASELINE configuration shade_ctx / sample_bsdf
+# (csrc/integrators.h) take a vertex's seven numbers from cmj_vertex_samples — two Kensler permutations per register, 16-bit
+# halves, v_pk_mul_lo_u16 / v_perm_b32 — and the roulette number from cmj_next_with_index, never from the one-by-one calls the
+# test above exercises.  Mask widths on both sides of the `w < 2048` shortcut, the largest the packed form takes (w = 0xffff),
+# one beyond it and a non-power-of-two (both fall back to the calls one by one: `batched` says which route ran).
+# Reference: /root/reference/corrmj.py:6-28 (permute), 60-117 (generate_1d / generate_2d).
+@pytest.mark.parametrize("spp", [1, 4, 16, 64, 256, 1024, 4096, 16384, 65536, 131072, 48, 2, 8, 32, 2048, 32768])
+def test_cmj_draws_of_the_path_kernels_bit_exact(spp):
+    scene = make_scene("path")
+    rng = np.random.default_rng(1000 + spp)
+    n, nvert = 400, 16
+    q = np.stack([rng.integers(0, 1024, n), rng.integers(0, 1024, n), rng.integers(0, spp, n)], 1).astype(np.int32)
+    q[0, 2] = spp - 1; q[1, 2] = 0                                  # both ends of the index range
+    pow2 = spp & (spp - 1) == 0
+    for seed in (0, 1, 853402567, 0xFFFFFFFF):
+        got, batched = scene.vertex_sampler_dump(torch.from_numpy(q).cuda(), spp, seed=seed, nvert=nvert)
+        assert batched == (pow2 and spp <= 65536), (spp, batched)   # cmj_can_batch: the route the renders of this spp take
+        got = got.cpu().numpy()
+        for k in range(n):
+            exp = oracle.sampler_dump(oracle.SAMPLER_CMJ, int(q[k, 0]), int(q[k, 1]), seed, spp, int(q[k, 2]), nvert=nvert)
+            assert exp.shape[0] == 2 + 7 * nvert + (nvert - 2)      # next2f, seven per vertex, a roulette draw from vertex 2 on
+            assert (got[k, :exp.shape[0]].view(np.uint32) == exp.view(np.uint32)).all(), (spp, seed, q[k])
+        # and the two routes of the library agree with each other on every draw
+        plain = scene.sampler_dump(torch.from_numpy(q).cuda(), spp, seed=seed, nvert=nvert).cpu().numpy()
+        assert (plain.view(np.uint32) == got.view(np.uint32)).all(), (spp, seed)
+
+
 def test_pmj02bn_draws_bit_exact_with_synthetic_tables():
     # the reference's pbrt tables are absent (.MISSING_LARGE_BLOBS): any table pins the arithmetic
     rng = np.random.default_rng(0)

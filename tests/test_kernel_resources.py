@@ -59,7 +59,7 @@ def pick(found, pattern):
 
 def test_backward_path_kernel_holds_sixteen_waves_per_cu_brute_force():
     """k_path_bwd<*, BruteAccel, *>: LDS is what decides — 8 blocks = 10,240 bytes per wave (100 pool slots, the scatter queue,
-    the tile origins; neither seeds nor cotangents: accel.h, ZDR_BWD_LEAN_LDS) — and 128 VGPRs."""
+    the tile origins; neither seeds nor cotangents: accel.h) — and 128 VGPRs."""
     for name, r in pick(kernels(), r"k_path_bwdILi[01]E10BruteAccel").items():
         assert r["group_segment_fixed_size"] <= 8 * LDS_BLOCK, (name, r)
         assert r["vgpr_count"] <= 128, (name, r)

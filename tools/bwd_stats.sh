@@ -1,8 +1,8 @@
-# How full are the trips, the sweep loop and the flushes of the cbox backward kernel?  A MEASUREMENT build (-DZDR_BWD_STATS: counters in
+# How full are the trips, the sweep loop and the flushes of the cbox backward kernel?  A MEASUREMENT build (-DZDR_MEASURE_STATS: counters in
 # k_path_bwd and scatter_flush, printed by zdr_render_backward) over the bench workload; the shipped library is rebuilt afterwards.
 #   bash tools/bwd_stats.sh [run_pass args]   -> stdout
 cd $GRAFT_REPO_ROOT
-ZDR_KERNEL_FLAGS="-DZDR_BWD_STATS" python -m zdr_amd.build --force > /dev/null 2>gpurun_out/bwd_stats_build.log || { tail -5 gpurun_out/bwd_stats_build.log; exit 1; }
+ZDR_KERNEL_FLAGS="-DZDR_MEASURE_STATS" python -m zdr_amd.build --force > /dev/null 2>gpurun_out/bwd_stats_build.log || { tail -5 gpurun_out/bwd_stats_build.log; exit 1; }
 timeout -k 10 200 python tools/run_pass.py --which bwd --iters 1 "$@" 2>&1 | grep -E "bwd stats|bwd:" | tail -2 | python -c "
 import sys, re
 for line in sys.stdin:

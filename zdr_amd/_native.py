@@ -15,7 +15,7 @@ COLLOCATED, DIRECT, PATH, UVGRAD = 0, 1, 2, 3
 SAMPLER_CMJ, SAMPLER_PMJ02BN = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 ABI_VERSION = 3                # ZDR_ABI_VERSION of the include/zdr.h this binding mirrors
-PRB_MODES = {"expectation": 0, "detached": 1}
+PRB_MODES = {"expectation": 0, "detached": 1, "literal": 2}
 INTEGRATORS = {"collocated": COLLOCATED, "direct": DIRECT, "path": PATH}   # render.py:65-69
 SAMPLERS = {"cmj": SAMPLER_CMJ, "corrmj": SAMPLER_CMJ, "pmj02bn": SAMPLER_PMJ02BN}
 ACCELS = {"auto": ACCEL_AUTO, "brute": ACCEL_BRUTE, "bvh": ACCEL_BVH}
@@ -25,7 +25,7 @@ COUNTER_NAMES = ("samples", "closest_rays", "closest_hits", "shadow_rays", "shad
 # every symbol include/zdr.h declares
 EXPORTS = ("zdr_version", "zdr_abi_version", "zdr_last_error", "zdr_scene_create", "zdr_scene_destroy", "zdr_scene_info",
            "zdr_scene_set_emissions", "zdr_scene_set_envmap", "zdr_scene_set_pmj02bn_tables", "zdr_render_forward", "zdr_render_backward",
-           "zdr_render_stats", "zdr_scene_check", "zdr_trace_closest", "zdr_trace_any", "zdr_sampler_dump", "zdr_path_dump", "zdr_debug_build_accel")
+           "zdr_render_stats", "zdr_scene_check", "zdr_trace_closest", "zdr_trace_any", "zdr_sampler_dump", "zdr_vertex_sampler_dump", "zdr_path_dump", "zdr_debug_build_accel")
 
 
 class CameraPOD(C.Structure):
@@ -84,6 +84,7 @@ def lib():
     L.zdr_trace_closest.argtypes = [vp, fp, C.c_uint32, ip, fp, vp]
     L.zdr_trace_any.argtypes = [vp, fp, C.c_uint32, ip, vp]
     L.zdr_sampler_dump.argtypes = [vp, C.c_int32, C.c_uint32, C.c_uint32, ip, C.c_uint32, C.c_int32, C.c_int32, fp, vp]
+    L.zdr_vertex_sampler_dump.argtypes = [vp, C.c_int32, C.c_uint32, C.c_uint32, ip, C.c_uint32, C.c_int32, C.c_int32, fp, C.POINTER(C.c_int32), vp]
     L.zdr_path_dump.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.c_uint32, C.c_int32, fp, vp]
     L.zdr_debug_build_accel.argtypes = [fp, C.c_uint32, C.c_int, fp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), ip, fp]
     for name in EXPORTS:

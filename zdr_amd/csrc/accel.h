@@ -19,32 +19,21 @@
 #define ZDR_MIN_WAVES_BVH 6    // 1 M triangles, forward ms at 1024^2 spp 32 with 4 / 5 / 6 / 7 / 8 waves per SIMD: 32.8 / 31.4 / 30.3 / 31.4 / 39.4
 #endif
 // The backward path kernel's waves per CU are decided by LDS, which gfx950 hands out in 128 blocks of 1,280 bytes per CU:
-// 16 waves = 8 blocks = 10,240 bytes per wave.  ZDR_BWD_LEAN_LDS (default): the kernel keeps neither the CMJ seeds nor the
-// pixel cotangents of its two item banks in LDS (2 KiB: a popped path hashes its seed again and loads its cotangent from the
-// image), which leaves room for a 100-slot record pool in 8 blocks — with 128 VGPRs (no spill since the kernarg reload) 16 waves
-// per CU instead of 12: 12.84 -> 11.37 ms on cbox 512^2 spp 256 (profiles/r3_bwd_records_and_atomics.txt).
-// 0: seeds and cotangents in LDS, 106 slots in 10 blocks, 12 waves per CU.
-#ifndef ZDR_BWD_LEAN_LDS
-#define ZDR_BWD_LEAN_LDS 1
-#endif
+// 16 waves = 8 blocks = 10,240 bytes per wave.  The kernel keeps neither the CMJ seeds nor the pixel cotangents of its two item
+// banks in LDS (a popped path hashes its seed again and loads its cotangent from the image), which leaves room for a 103-slot
+// record pool in 8 blocks — with 128 VGPRs (no spill since the kernarg reload) 16 waves per CU instead of 12: 12.84 -> 11.37 ms on
+// cbox 512^2 spp 256 (profiles/r3_bwd_records_and_atomics.txt).
 #ifndef ZDR_MIN_WAVES_BWD
-#define ZDR_MIN_WAVES_BWD (ZDR_BWD_LEAN_LDS ? 4 : 3)
+#define ZDR_MIN_WAVES_BWD 4
 #endif
 #ifndef ZDR_POOL_SLOTS
-#define ZDR_POOL_SLOTS (ZDR_BWD_LEAN_LDS ? 103 : 106)       // brute force: 10,176 bytes of LDS per wave (103 x 81 + the scatter queue + 48) / 12 waves per CU
+#define ZDR_POOL_SLOTS 103            // brute force: 10,176 bytes of LDS per wave (103 x 81 + the scatter queue + 48)
 #endif
 #ifndef ZDR_POOL_SLOTS_BVH
-#define ZDR_POOL_SLOTS_BVH (ZDR_BWD_LEAN_LDS ? 72 : 57)     // BVH: + the traversal stack (ZDR_BVH_LDS_STACK_BWD entries x 256 bytes), 8 blocks either way
+#define ZDR_POOL_SLOTS_BVH 72         // BVH: + the traversal stack (ZDR_BVH_LDS_STACK_BWD entries x 256 bytes), 8 blocks as well
 #endif
 #ifndef ZDR_MIN_WAVES_BWD_BVH
 #define ZDR_MIN_WAVES_BWD_BVH 4
-#endif
-// vertex records of the backward kernel kept in LDS (4.25 KiB per wave each)
-#ifndef ZDR_LDS_VERTICES
-#define ZDR_LDS_VERTICES 2
-#endif
-#ifndef ZDR_LDS_VERTICES_BVH
-#define ZDR_LDS_VERTICES_BVH 1
 #endif
 
 
@@ -171,11 +160,9 @@ ZD void brute_resolve(const DScene &S, Hit &h, int prim, f3 o, f3 d) {
 
 struct BruteAccel {
     static constexpr bool kNeedsLds = false;
-    ZD static void prepare(const DScene &, int *) {}
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES, kMinWavesFwdEnv = ZDR_MIN_WAVES_ENV;
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD;
     static constexpr int kPoolSlots = ZDR_POOL_SLOTS;        // record pool of the backward path kernel (zdr_kernels.hip)
-    static constexpr int kLdsVertices = ZDR_LDS_VERTICES;    // scratch records thrash L2 on cbox (1 instead of 2: 16.7 -> 19.0 ms)
     static constexpr bool kFuseRays = false;                 // one walk over the pairs for both rays of a vertex measured no gain
     ZD static Hit closest(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         Hit h; h.slot = -1; h.u = 0.0f; h.v = 0.0f; h.t = tmax;
@@ -252,16 +239,12 @@ ZD float qbox_entry(uint32_t nxq, uint32_t nyq, uint32_t nzq, uint32_t fxq, uint
     return (tn <= tf) ? tn : 3.0e38f;
 }
 
-#ifndef ZDR_BVH_FUSED_WALK
-#define ZDR_BVH_FUSED_WALK 1
-#endif
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
     static constexpr int kMinWavesFwdEnv = ZDR_MIN_WAVES_BVH;
     static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // 6 waves per SIMD (<= 80 VGPRs: the path state that is cold during the walk is spilled around it); sweep at ZDR_MIN_WAVES_BVH
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
     static constexpr int kPoolSlots = ZDR_POOL_SLOTS_BVH;
-    static constexpr int kLdsVertices = ZDR_LDS_VERTICES_BVH;    // <= 128 VGPRs give 15 waves per CU instead of 11 (109 -> 94 ms on 1 M triangles)
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
     static constexpr bool kFuseRays = true;                  // path_shade hands over both rays of a vertex at once (walk<true, true>)
     // 4-wide BVH, one 64-byte quantised node per visit (4 dwordx4 loads), nearest hit child first.
@@ -272,17 +255,6 @@ struct BvhAccel {
         int sp, id, cnt, budget;
     };
     ZD static int root_count(const DScene &S) { return (S.nnodes == 0) ? S.ntris : 0; }
-    // Called once by the whole wave before its first walk: the top S.lds_top nodes of the tree go to LDS behind the stack.
-    ZD static float4 *top_nodes(const DScene &S, int *stack) { return (float4 *)(stack + S.lds_stack * 64); }
-    ZD static void prepare(const DScene &S, int *stack) {
-#ifndef ZDR_BVH_TOP_CACHE
-        return;
-#endif
-        float4 *top = top_nodes(S, stack);
-        for (int i = threadIdx.x & 63; i < 4 * S.lds_top; i += 64) top[i] = S.nodes[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
     // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it impossible for a wave to
     // spin forever whatever the node data or the ray (NaNs) look like.
     ZD static int walk_budget(const DScene &S) { return (S.debug_bvh_budget > 0) ? S.debug_bvh_budget : 2 * (S.nnodes + S.ntris) + 8; }
@@ -309,13 +281,6 @@ struct BvhAccel {
     ZD static Fetched fetch(const DScene &S, int *stack, Walker &w) {
         Fetched f;
         f.dead = (--w.budget < 0);
-#ifdef ZDR_BVH_TOP_CACHE
-        if ((w.cnt == 0) & (w.id < S.lds_top)) {              // the top of the tree: from this wave's LDS copy (experiment, scene.h)
-            const float4 *q = top_nodes(S, stack) + 4 * w.id;
-            f.n0 = q[0]; f.n1 = q[1]; f.n2 = q[2]; f.n3 = q[3];
-            return f;
-        }
-#endif
         // nodes and plane records live in one allocation (zdr_api.cpp): scalar base + 32-bit byte offset (a node is 64 bytes, a triangle 48) —
         // three VALU instead of a branch, a four-pass v_mad_i64 and 64-bit shifts and adds in every trip
         uint32_t off = (w.cnt == 0) ? ((uint32_t)w.id << 6) : (uint32_t)w.id * 48u + S.isect_off;
@@ -420,7 +385,6 @@ struct BvhAccel {
         int deep[ZDR_BVH_STACK];
         Walker w;
         if (first) start(S, w, oA, dA, tminA, tmaxA); else start(S, w, oB, dB, tminB, tmaxB);
-#if ZDR_BVH_FUSED_WALK
         // ONE loop with a wave-uniform exit: a lane whose first ray ends starts its second ray inside the trip, under its own exec
         // mask.  (Written as `for (;;) { if (step()) continue; ...restart...; continue; }` the compiler splits the loop in two nested
         // ones — an inner one that runs until EVERY lane's current ray has ended, an outer one that restarts them together — and the
@@ -438,23 +402,6 @@ struct BvhAccel {
             }
         }
         if (HAS_B && needB) { hit = w.h; hit_barycentrics(S, hit, oB, dB); }
-#else
-        if (!active) return;
-        for (;;) {
-            if (step(S, stack, LN, deep, w, first)) continue;
-            // this lane's current ray has ended
-            if (w.budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);   // the walk was cut short: whatever it returns is not a result
-            if (first) {
-                occ = w.h.slot >= 0;
-                if (!HAS_B || !needB) break;
-                first = false;
-                start(S, w, oB, dB, tminB, tmaxB);
-                continue;
-            }
-            break;
-        }
-        if (HAS_B && !first && needB) { hit = w.h; hit_barycentrics(S, hit, oB, dB); }
-#endif
     }
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         bool occ; Hit h;

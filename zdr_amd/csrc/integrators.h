@@ -7,6 +7,7 @@
 #include "accel.h"
 #include "internal.h"
 #include "microfacet.h"
+#include "zdr.h"
 
 ZD float tent_warp1(float u) {                                   // camera.py:20-31, radius 1
     return (u < 0.5f) ? (fsqrt(2.0f * u) - 1.0f) : (1.0f - fsqrt(2.0f - 2.0f * u));
@@ -334,6 +335,9 @@ ZD bool sample_bsdf(const RenderCfg &R, const SamplerCfg &C, const ShadeCtx &x, 
             // expectation then depends on q(material); the sweep differentiates through it (sweep_vertex).
             pv.rr = rr_kind;
             if (rr_kind == 2) pv.bnorm = ps.beta;
+            // ZDR_PRB_LITERAL (prb.py:157-163): no roulette fields; bnorm carries beta f / pdf, the part of the literal seed
+            // beta / pdf * Le that is not already in Q and in the arriving radiance (sweep_vertex)
+            if (R.prb_mode == ZDR_PRB_LITERAL) { pv.rr = 0; pv.bnorm = beta_in * (f * inv_p); }
         }
     }
     ps.depth++;
@@ -498,11 +502,12 @@ ZD int primary_pop(const DScene &S, const SamplerCfg &C, bool idle, const uint32
 //   e = {b = beta leaving (rr == 2) | (-1,0,0) (rr == 1) | 0, dln(pdf)/dr}
 struct PackedVertex { float4 a, b, c, d, e; };
 
-// detached (ZDR_PRB_DETACHED): the MIS weights and the Russian-roulette factors are constants — no neeM, no RR fields, no score
-ZD PackedVertex pack_vertex(const PathVertex &v, f3 g, bool detached = false) {
+// mode (zdr.h): ZDR_PRB_DETACHED — the MIS weights and the Russian-roulette factors are constants: no neeM, no RR fields, no score;
+// ZDR_PRB_LITERAL — as detached, and e.xyz = beta f / pdf for the literal BSDF-sample seed of prb.py:162
+ZD PackedVertex pack_vertex(const PathVertex &v, f3 g, int mode = ZDR_PRB_EXPECTATION) {
     PackedVertex p;
     p.a = brdf_grad(v.cL, v.dfLdr, v.bW * g);
-    if (!detached) p.a.w -= dot(g, v.neeM);
+    if (mode == ZDR_PRB_EXPECTATION) p.a.w -= dot(g, v.neeM);
     f3 Q = v.bpq * v.c;
     float r = (v.c > 0.0f) ? v.dfdr * rcp(v.c) : 0.0f;
     p.b = make_float4(Q.x, Q.y, Q.z, r);
@@ -510,7 +515,9 @@ ZD PackedVertex pack_vertex(const PathVertex &v, f3 g, bool detached = false) {
     f3 gA = g * v.fLW;
     p.d = make_float4(gA.x, gA.y, gA.z, v.uv.y);
     f3 e = (v.rr == 2) ? v.bnorm : ((v.rr == 1) ? mk3(-1.0f, 0.0f, 0.0f) : mk3(0.0f));
-    p.e = detached ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(e.x, e.y, e.z, v.dlnp);
+    p.e = make_float4(e.x, e.y, e.z, v.dlnp);
+    if (mode == ZDR_PRB_DETACHED) p.e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (mode == ZDR_PRB_LITERAL) p.e = make_float4(v.bnorm.x, v.bnorm.y, v.bnorm.z, 0.0f);
     return p;
 }
 
@@ -522,10 +529,12 @@ ZD PackedVertex pack_vertex(const PathVertex &v, f3 g, bool detached = false) {
 struct SweepState { f3 A, Lv; float s, Z, tw; };
 
 // One step (prb.py:105-187 with the corrected weight, App. B-3): consumes a vertex, returns its gradient.
-ZD float4 sweep_vertex(const PackedVertex &p, SweepState &S, f2 &uv) {
+ZD float4 sweep_vertex(const PackedVertex &p, SweepState &S, f2 &uv, int mode = ZDR_PRB_EXPECTATION) {
     const f3 w = mk3(0.212671f, 0.715160f, 0.072169f);           // prb.py:80
     f3 Aeff = S.A;
-    if (p.e.x < 0.0f) {                                          // stochastic RR vertex
+    if (mode == ZDR_PRB_LITERAL) {                               // prb.py:162: (beta / pdf) * Le_remaining * le_grad, Le_remaining = beta T Li
+        Aeff = mk3(p.e.x, p.e.y, p.e.z) * S.Lv;
+    } else if (p.e.x < 0.0f) {                                   // stochastic RR vertex
         Aeff = S.A + w * S.s; S.s = 0.0f; S.Z = 0.0f;
     } else if (p.e.x + p.e.y + p.e.z > 0.0f) {                   // renormalising RR vertex
         f3 b = mk3(p.e.x, p.e.y, p.e.z);

@@ -28,13 +28,13 @@ struct RenderCfg {
     int32_t shard_skew;                         // row r of the tile grid is numbered starting at column r * skew (1 when sharded: diagonals; 0 otherwise)
     int32_t use_tent, max_depth, rr_depth;
     int32_t tex_h, tex_w;
-    int32_t prb_detached;             // backward, path: roulette factors and MIS weights held constant (zdr.h, ZDR_PRB_DETACHED)
+    int32_t prb_mode;                 // backward, path: ZDR_PRB_* of zdr.h (expectation / detached: roulette factors and MIS weights held constant / literal: the weight of prb.py:162)
     int32_t cell_copies;              // backward: replicas of the staging-cell array (scene.h: few texels), >= 1
     float two_over_w, two_over_h, aspect;      // integrator.py:22-23
     float inv_spp;                             // 1 / spp as computed by IEEE division
     float alpha;                               // (sample_end - sample_begin) / spp
     float cam_o[3], cam_fwd[3], cam_right[3], cam_upp[3], cam_tan;   // camera.py:12-15
-    int32_t debug_no_scatter;         // timing-only ablations (env ZDR_DEBUG_NO_SCATTER): 1 gradients computed, not added; 2 atomics confined to 64 KiB; 3 no sweep; 4 / 5 the sweep loop cut after 2 / 1 iterations (the tail of long paths dropped: what any scheme that defers it could save at most); 6 queue and flush run, no atomic is issued; 7 / 8 records beyond the LDS ones not read back / not written either
+    int32_t debug_no_scatter;         // measurement builds only (-DZDR_MEASURE, env ZDR_DEBUG_NO_SCATTER; always 0 in the product): timing-only ablations — 1 gradients computed, not added; 2 atomics confined to 64 KiB; 3 no sweep; 4 / 5 the sweep loop cut after 2 / 1 iterations (the tail of long paths dropped: what any scheme that defers it could save at most); 6 queue and flush run, no atomic is issued
 };
 
 struct KernelIO {
@@ -57,6 +57,6 @@ int zdr_launch_zero(void *p, size_t bytes, hipStream_t stream);   // kernel zero
 int zdr_launch_trace(const DScene &S, int accel_is_bvh, int any, const float *rays, uint32_t n,
                      int32_t *out_i, float *out_f, hipStream_t stream);
 int zdr_launch_sampler_dump(const SamplerCfg &C, const int32_t *queries, uint32_t n, int32_t nvert,
-                            int32_t rr_depth, float *out, hipStream_t stream);
+                            int32_t rr_depth, float *out, int as_path_kernels, int *batched, hipStream_t stream);
 int zdr_launch_path_dump(const DScene &S, const RenderCfg &R, const SamplerCfg &C, const KernelIO &io, int accel_is_bvh,
                          const int32_t *queries, uint32_t n, int32_t maxv, float *out, hipStream_t stream);

@@ -183,7 +183,7 @@ ZD uint32_t permutation_element2(uint32_t i, uint32_t w, uint32_t pa, uint32_t p
 }
 
 struct VertexSamples { float u_pick, u_prim; f2 u_pt; float u_lobe; f2 u_dir; uint32_t i_rr; };   // i_rr: the permuted index of the NEXT 1-D draw (Russian roulette), should the vertex make it
-ZD bool cmj_can_batch(const SamplerCfg &c) {                        // wave-uniform
+__host__ ZD bool cmj_can_batch(const SamplerCfg &c) {               // wave-uniform (host: zdr_vertex_sampler_dump reports which route its kernel took)
     return c.spp_pow2 && c.res_pow2 && c.spp <= 65536u && c.w == c.spp - 1u && c.resw_x == c.res_x - 1u && c.resw_y == c.res_y - 1u;
 }
 ZD VertexSamples cmj_vertex_samples(const SamplerCfg &c, Sampler &s) {

@@ -18,19 +18,8 @@
 #ifndef ZDR_BVH_LDS_STACK_BWD
 #define ZDR_BVH_LDS_STACK_BWD 10   // (6 until the backward kernel's records moved into a pool: 1 M triangles, 1024^2 spp 32, stack entries / pool slots in the same 8 LDS blocks: 4 / 90 35.2 ms, 6 / 84 34.0, 10 / 72 32.8, 12 / 65 32.8, 14 / 59 32.8)
 #endif
-// The top of the tree in LDS (a per-wave copy of nodes 0 .. K-1 behind the stack; the builder numbers the top of the tree breadth-first):
-// a divergent 64-byte fetch costs the vector-memory path ~3 cycles per ACTIVE lane from L2 against 20-26 cycles per WAVE from LDS
-// (tools/micro/gather_rate.hip, profiles/r3_gather_rate.txt) — and yet it measured SLOWER on the 1 M-triangle scene (K = 5: equal, 21: +5 %,
-// 64: +20 %; profiles/r3_bvh_lds_top.txt): the top nodes are the ones every wave finds in L1 anyway, the extra branch in the fetch and the
-// LDS taken from the occupancy cost more.  Compiled out unless ZDR_BVH_TOP_CACHE is defined (then ZDR_BVH_LDS_TOP / _BWD nodes, env ZDR_BVH_LDS_TOP).
-#ifdef ZDR_BVH_TOP_CACHE
-#ifndef ZDR_BVH_LDS_TOP
-#define ZDR_BVH_LDS_TOP 21
-#endif
-#ifndef ZDR_BVH_LDS_TOP_BWD
-#define ZDR_BVH_LDS_TOP_BWD 5
-#endif
-#endif
+// (A per-wave LDS copy of the top of the tree measured slower — K = 5 nodes: equal, 21: +5 %, 64: +20 %, profiles/r3_bvh_lds_top.txt: the top nodes
+// are the ones every wave finds in L1 anyway — and was removed in round 4; the code is kept in profiles/r4_pruned_experiment_branches.patch.)
 
 // Per-slot records, 16-byte aligned so a record is fetched with dwordx4 loads:
 //   isect[3*slot + {0,1,2}] = {n, n.p0} {nu, du} {nv, dv}              (48 B, plane-form triangle test)
@@ -65,7 +54,6 @@ struct DScene {
     const char *walk_base; uint32_t isect_off;   // BVH: nodes[] and isect[] live in ONE allocation, nodes first; isect[] starts isect_off bytes behind walk_base
     int32_t stack_entries;          // per-lane traversal stack entries this tree needs
     int32_t lds_stack;              // how many of them this launch keeps in LDS (dynamic LDS: lds_stack x 64 ints per wave), set by the launcher
-    int32_t lds_top;                // nodes [0, lds_top) — the top of the tree, numbered breadth-first by the builder — are copied into each wave's LDS behind its stack (accel.h), set by the launcher
     // Device error word (sticky until the host reads it: zdr_scene_check, zdr_render_stats, ZDR_CHECK=1).  A watchdog
     // that ends work early ORs its bit in, so an incomplete image or gradient can never pass as a good one.
     unsigned int *error_word;
@@ -73,6 +61,7 @@ struct DScene {
 };
 #define ZDR_DEVERR_STALL 1u          // a persistent path wave left its loop without having drained its work
 #define ZDR_DEVERR_BVH_BUDGET 2u     // a BVH walk ran out of its iteration budget (corrupt nodes or a NaN ray that never ends)
+#define ZDR_DEVERR_POOL 4u           // a backward path wave ended with slots of its record pool leaked or doubly allocated (zdr_kernels.hip, lds_free)
 ZD void raise_device_error(const DScene &S, unsigned int bit) { if (S.error_word) atomicOr(S.error_word, bit); }
 
 struct Hit { int slot; float u, v, t; };   // slot < 0: miss (LuisaCompute Hit{inst, prim, bary, ray_t})
@@ -164,7 +153,7 @@ struct ScatterQueue {                // pointers into this wave's LDS block
     int copy_base;                   // first cell of this wave's copy of the staging array
     int ncells;                      // (tex_h + 1) x (tex_w + 1)
     float *lds_cells;                // != nullptr: the whole cell array lives here (ncells <= ZDR_LDS_CELLS)
-#ifdef ZDR_BWD_STATS
+#ifdef ZDR_MEASURE_STATS
     unsigned long long st_flushes, st_entries, st_dups;   // measurement build: flushes, entries flushed, entries whose cell an earlier entry of the same flush holds
 #endif
 };
@@ -176,7 +165,7 @@ ZD ScatterQueue scatter_queue_init(float *lds, int tex_h, int tex_w, int cell_co
     ScatterQueue q;
     q.cell = (int *)lds; q.g = lds + ZDR_SCATTER_CAP; q.ox = lds + 5 * ZDR_SCATTER_CAP; q.oy = lds + 6 * ZDR_SCATTER_CAP;
     q.count = 0;
-#ifdef ZDR_BWD_STATS
+#ifdef ZDR_MEASURE_STATS
     q.st_flushes = q.st_entries = q.st_dups = 0;
 #endif
     q.ncells = (tex_h + 1) * (tex_w + 1);
@@ -215,7 +204,7 @@ ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells, int tex_h, int
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#ifdef ZDR_BWD_STATS
+#ifdef ZDR_MEASURE_STATS
     if (q.count > 0) {
         bool dup = false;
         if (lane < q.count) for (int k = 0; k < lane; k++) dup = dup || (q.cell[k] == q.cell[lane]);

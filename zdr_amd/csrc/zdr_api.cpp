@@ -801,8 +801,8 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     // 256 CUs x 4 SIMDs busy with several waves each and to let the dispatcher balance uneven tiles
     R.tiles_x = (p->x1 - p->x0 + 7) / 8; R.tiles_y = (p->y1 - p->y0 + 7) / 8;
     uint32_t ns = p->sample_end - p->sample_begin;
-    if (p->prb_mode != ZDR_PRB_EXPECTATION && p->prb_mode != ZDR_PRB_DETACHED) return fail(ZDR_E_INVALID, "unknown prb_mode");
-    R.prb_detached = p->prb_mode == ZDR_PRB_DETACHED;
+    if (p->prb_mode != ZDR_PRB_EXPECTATION && p->prb_mode != ZDR_PRB_DETACHED && p->prb_mode != ZDR_PRB_LITERAL) return fail(ZDR_E_INVALID, "unknown prb_mode");
+    R.prb_mode = p->prb_mode;
     R.shard_count = p->tile_shard_count > 1 ? p->tile_shard_count : 1;
     R.shard_index = p->tile_shard_count > 1 ? p->tile_shard_index : 0;
     R.shard_skew = R.shard_count > 1 ? 1 : 0;
@@ -817,7 +817,9 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     long maxc = std::max<long>(1, ns / min_chunk);
     long nchunks = std::max<long>(1, std::min(want, maxc));
     if (p->integrator == ZDR_UVGRAD) nchunks = 1;        // four-channel output, written directly
+#ifdef ZDR_MEASURE   // timing-only ablations exist in measurement builds alone (zdr_kernels.hip, ZDR_ABLATE)
     if (const char *e = getenv("ZDR_DEBUG_NO_SCATTER")) R.debug_no_scatter = atoi(e);
+#endif
     R.chunk = ns ? (uint32_t)((ns + nchunks - 1) / nchunks) : 1;
     R.nchunks = ns ? (int32_t)((ns + R.chunk - 1) / R.chunk) : 0;
     return ZDR_OK;
@@ -871,6 +873,7 @@ static int check_device_error(zdr_scene *s, hipStream_t st) {
     std::string m = "device watchdog tripped:";
     if (h & ZDR_DEVERR_STALL) m += " a persistent path wave stopped without draining its work items;";
     if (h & ZDR_DEVERR_BVH_BUDGET) m += " a BVH walk exceeded its iteration budget;";
+    if (h & ZDR_DEVERR_POOL) m += " a backward wave ended with record-pool slots leaked or handed out twice;";
     return fail(ZDR_E_HIP, m + " results since the last check are incomplete");
 }
 
@@ -940,7 +943,7 @@ extern "C" int zdr_render_forward(zdr_scene *s, const zdr_render_params *p, cons
 extern "C" int zdr_render_backward(zdr_scene *s, const zdr_render_params *p, const float *d_image, const float *material,
                                    float *d_material, void *stream) {
     if (!d_image || !d_material) return fail(ZDR_E_INVALID, "null gradient buffer");
-#ifdef ZDR_BWD_STATS   // measurement build (tools/bwd_stats.py): the path backward kernel counts its trips, sweep iterations and flushes
+#ifdef ZDR_MEASURE_STATS   // measurement build (tools/bwd_stats.sh): the path backward kernel counts its trips, sweep iterations and flushes
     if (s) { (void)hipSetDevice(s->device); (void)hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream); }
     int rc = render_common(s, p, material, nullptr, d_image, d_material, 1, 0, stream);
     if (!rc) {
@@ -1004,6 +1007,18 @@ extern "C" int zdr_sampler_dump(zdr_scene *s, int32_t sampler, uint32_t seed, ui
     HIPCHK(hipSetDevice(s->device));
     SamplerCfg C;
     int rc = make_sampler_cfg(s, sampler, seed, spp, C); if (rc) return rc;
-    if (zdr_launch_sampler_dump(C, queries, n, nvert, rr_depth, out, (hipStream_t)stream)) return fail(ZDR_E_HIP, "sampler dump launch failed");
+    if (zdr_launch_sampler_dump(C, queries, n, nvert, rr_depth, out, 0, nullptr, (hipStream_t)stream)) return fail(ZDR_E_HIP, "sampler dump launch failed");
+    return ZDR_OK;
+}
+
+extern "C" int zdr_vertex_sampler_dump(zdr_scene *s, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries, uint32_t n,
+                                       int32_t nvert, int32_t rr_depth, float *out, int32_t *batched, void *stream) {
+    if (!s || !queries || !out || nvert < 0) return fail(ZDR_E_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(s->device));
+    SamplerCfg C;
+    int rc = make_sampler_cfg(s, sampler, seed, spp, C); if (rc) return rc;
+    int b = 0;
+    if (zdr_launch_sampler_dump(C, queries, n, nvert, rr_depth, out, 1, &b, (hipStream_t)stream)) return fail(ZDR_E_HIP, "sampler dump launch failed");
+    if (batched) *batched = b;
     return ZDR_OK;
 }

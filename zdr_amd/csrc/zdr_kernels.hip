@@ -6,10 +6,12 @@
 // run of tiles: primary-hit texel footprints of neighbouring tiles then share that XCD's L2.  The path kernels are
 // persistent waves that draw items from per-XCD counters and treat lanes as workers (see k_path).
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 #include "integrators.h"
 #include "zdr.h"
 
@@ -171,46 +173,49 @@ struct ItemBanks {
     uint32_t inflight[2];    // parked + running paths of each bank (wave-uniform)
 };
 
-// ZDR_KARG_RELOAD (experiment): the persistent kernels read their launch constants (scene pointers, camera, sampler grid ...)
-// through a pointer to the kernarg segment that is laundered once per trip, so a constant is s_load-ed again where a trip uses it
-// instead of being kept for the whole kernel in an SGPR that is spilled to a VGPR lane (v_readlane / v_writelane / s_nop on the
-// VALU port, 320 reloads in k_path<cmj, brute>).
-#ifndef ZDR_RECORD_POOL
-#define ZDR_RECORD_POOL 1      // backward path kernel: vertex records in a per-wave LDS pool (0: first LV vertices per lane in LDS, the rest in scratch)
-#endif
-#ifndef ZDR_KARG_RELOAD
-#define ZDR_KARG_RELOAD 1
-#endif
+// The persistent kernels read their launch constants (scene pointers, camera, sampler grid ...) through a pointer to the kernarg
+// segment that is laundered once per trip, so a constant is s_load-ed again where a trip uses it instead of being kept for the whole
+// kernel in an SGPR that is spilled to a VGPR lane (v_readlane / v_writelane / s_nop on the VALU port: 320 reloads in
+// k_path<cmj, brute> before; profiles/r3_bwd_records_and_atomics.txt).  PathKArgs must be the kernels' parameter list, in order:
+// every kernel that uses the macros is declared through ZDR_PATH_KERNEL_PARAMS, and the layout rules the kernarg segment follows
+// (each by-value struct at its natural alignment, at most 8 here) are asserted below.
 struct PathKArgs { DScene S; RenderCfg R; SamplerCfg C; KernelIO io; };
+#define ZDR_PATH_KERNEL_PARAMS DScene S_, RenderCfg R_, SamplerCfg C_, KernelIO io_
+static constexpr size_t zdr_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static_assert(std::is_trivially_copyable<PathKArgs>::value && std::is_standard_layout<PathKArgs>::value, "kernel arguments are copied bytewise");
+static_assert(offsetof(PathKArgs, S) == 0, "first kernel argument at offset 0 of the kernarg segment");
+static_assert(offsetof(PathKArgs, R) == zdr_align_up(sizeof(DScene), alignof(RenderCfg)), "PathKArgs does not mirror the kernarg packing");
+static_assert(offsetof(PathKArgs, C) == zdr_align_up(offsetof(PathKArgs, R) + sizeof(RenderCfg), alignof(SamplerCfg)), "PathKArgs does not mirror the kernarg packing");
+static_assert(offsetof(PathKArgs, io) == zdr_align_up(offsetof(PathKArgs, C) + sizeof(SamplerCfg), alignof(KernelIO)), "PathKArgs does not mirror the kernarg packing");
+static_assert(alignof(DScene) <= 8 && alignof(RenderCfg) <= 8 && alignof(SamplerCfg) <= 8 && alignof(KernelIO) <= 8, "an over-aligned member would change the kernarg packing");
 typedef __attribute__((address_space(4))) const char karg_byte_t;
 ZD const PathKArgs &kargs_fresh() {
     karg_byte_t *p = (karg_byte_t *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return *(const PathKArgs *)p;
 }
-#if ZDR_KARG_RELOAD
 #define ZDR_KARGS_BEGIN const PathKArgs *ka = &kargs_fresh();
 #define ZDR_KARGS_REFRESH ka = &kargs_fresh();
+// Timing-only ablations of the backward kernels exist in measurement builds alone (-DZDR_MEASURE, tools/): the product reads no
+// ZDR_DEBUG_NO_SCATTER and every `ZDR_ABLATE == n` below folds to false.
+#ifdef ZDR_MEASURE
+#define ZDR_ABLATE (R.debug_no_scatter)
 #else
-#define ZDR_KARGS_BEGIN const DScene &S = S_; const RenderCfg &R = R_; const SamplerCfg &C = C_; const KernelIO &io = io_;
-#define ZDR_KARGS_REFRESH
+#define ZDR_ABLATE 0
 #endif
 
 template <int SK, class A, bool STATS, bool ENV>
-__global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) void k_path(DScene S_, RenderCfg R_, SamplerCfg C_, KernelIO io_) {
+__global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) void k_path(ZDR_PATH_KERNEL_PARAMS) {
     ZDR_KARGS_BEGIN
-#if ZDR_KARG_RELOAD
 #define S (ka->S)
 #define R (ka->R)
 #define C (ka->C)
 #define io (ka->io)
-#endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ uint32_t lds_perm[2 * WAVE];
     __shared__ int lds_origin[4];
     __shared__ float lds_sum[2 * 3 * WAVE];
     const int lane = threadIdx.x;
-    A::prepare(S, lds);
     Counters cnt;
 #pragma unroll
     for (int i = 0; i < 8; i++) cnt.c[i] = 0;
@@ -301,77 +306,54 @@ __global__ __launch_bounds__(WAVE, ENV ? A::kMinWavesFwdEnv : A::kMinWavesFwd) v
         if (stall > 4) { raise_device_error(S, ZDR_DEVERR_STALL); break; }   // cannot happen (every branch above makes progress); never spin on the GPU, never end silently
     }
     flush_counters<STATS>(io, cnt);
-#if ZDR_KARG_RELOAD
 #undef S
 #undef R
 #undef C
 #undef io
-#endif
 }
 
 // PRB backward with ONE traversal.  Each trip a live lane shades one vertex of its path (same trip
 // order, primary queue, pixel-free lanes, persistent waves and item banks as k_path) and appends it to its record list.  The
 // records (5 float4 + a link to the path's previous one) live in a per-wave LDS POOL, see below; the few that find no slot go to
-// per-lane scratch.  (ZDR_RECORD_POOL=0: the first ZDR_LDS_VERTICES vertices of a path in lane-owned LDS rows
-// [vertex][float4][lane], the others — 17 % of the records on cbox — in scratch.)
-// When a path ends, a short wave-uniform loop sweeps its records last to first and queues the
+// per-lane scratch.  When a path ends, a short wave-uniform loop sweeps its records last to first and queues the
 // gradients; all queue traffic happens at reconverged points so the whole wave takes part in a flush.
 // Keeping the records out of scratch is what matters: 2.3 KB of scratch per lane thrashed L2 (113 GB of
 // fabric traffic per launch, 13 of 37 ms, round 1); the last 17 % cost 1.4 ms of 13.6 (profiles/r3_bwd_records_and_atomics.txt).
+// Neither the CMJ seeds nor the pixel cotangents of the two item banks are kept in LDS (a popped path hashes its seed again and
+// loads its cotangent from the image): that leaves room for the pool in 8 of gfx950's 1,280-byte LDS blocks, 16 waves per CU.
+// (The lane-owned record rows, the 12-wave layout with seeds and cotangents in LDS and the LDS padding experiment that preceded
+// this are kept as profiles/r4_pruned_experiment_branches.patch.)
+typedef unsigned int zdr_u4 __attribute__((ext_vector_type(4)));
 template <int SK, class A, bool ENV>
-__global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, RenderCfg R_, SamplerCfg C_, KernelIO io_) {
+__global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(ZDR_PATH_KERNEL_PARAMS) {
     ZDR_KARGS_BEGIN
-#if ZDR_KARG_RELOAD
 #define S (ka->S)
 #define R (ka->R)
 #define C (ka->C)
 #define io (ka->io)
-#endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ __attribute__((aligned(16))) float lds_q[ZDR_SCATTER_LDS_FLOATS];   // the queue writes g as one float4
-    constexpr int LV = A::kLdsVertices;                     // LDS budget for vertex records, in rows of 64 records of 68 bytes
-#if ZDR_RECORD_POOL
     // The records of all paths of the wave share ONE pool of NS slots (80 bytes + a link each): a lane takes its home slot
     // (slot == lane) when that is free and otherwise the lowest free one, and gives the slot back when the sweep has read it.
-    // A lane-owned layout [vertex k][lane] kept only the first LV vertices of a path in LDS and sent 17 % of the records
-    // to scratch, whose reads — queued behind the flush's atomics, the same counter — cost 1.4 ms of 13.6.
     constexpr int NS = A::kPoolSlots;
     static_assert(NS >= 16 && NS <= 128, "the free mask is two 64-bit words");
     __shared__ float4 lds_pool[5 * NS];                     // [float4 f][slot]
     __shared__ unsigned char lds_link[NS];                  // slot of the path's previous record (255: in scratch; a path's first record links to nothing and its link is never followed).  One byte: three more slots fit
-    __shared__ __attribute__((aligned(16))) unsigned int lds_free[4];   // bit s set: slot s is free (the sweep gives slots back with ds_or)
-#else
-    __shared__ float4 lds_rec[LV * 4 * WAVE];
-    __shared__ float lds_dlnp[LV * WAVE];
-#endif
-#if ZDR_BWD_LEAN_LDS
-    const uint32_t *lds_perm = nullptr;
-    __shared__ int lds_origin[4];
-#else
-    __shared__ uint32_t lds_perm[2 * WAVE];                 // per item bank (see k_path): CMJ seeds, tile origin,
-    __shared__ int lds_origin[4];
-    __shared__ float lds_leg[2 * 3 * WAVE];                 // and the pixel cotangents / spp
-#endif
-#ifdef ZDR_BWD_LDS_PAD                                      // experiment: what fewer waves per CU cost (profiles/r2_bwd_occupancy.txt)
-    __shared__ float lds_pad[ZDR_BWD_LDS_PAD];
-    if (R.width < 0) lds_pad[threadIdx.x] = 1.0f;
-    if (R.height < 0) io.cells[0] = lds_pad[threadIdx.x ^ 1];
-#endif
+    // bit s set: slot s is free.  The only state lanes share: lane 0 stores the mask after an allocation, the sweep's lanes OR freed
+    // slots in, every lane reads it before the next allocation.  All three accesses are volatile or atomic and stand between
+    // wavefront-scope fences, so the protocol does not rest on what the optimiser happens to do with plain LDS accesses.
+    __shared__ __attribute__((aligned(16))) unsigned int lds_free[4];
+    __shared__ int lds_origin[4];                           // first pixel of each item bank's tile
     const int lane = threadIdx.x;
-    A::prepare(S, lds);
-#if ZDR_RECORD_POOL
+    constexpr unsigned long long all_lo = (NS >= 64) ? ~0ull : ((1ull << (NS & 63)) - 1ull);
+    constexpr unsigned long long all_hi = (NS > 64) ? ((NS >= 128) ? ~0ull : ((1ull << ((NS - 64) & 63)) - 1ull)) : 0ull;
     if (lane < 4) {
-        const unsigned long long all_lo = (NS >= 64) ? ~0ull : ((1ull << (NS & 63)) - 1ull);
-        const unsigned long long all_hi = (NS > 64) ? ((NS >= 128) ? ~0ull : ((1ull << ((NS - 64) & 63)) - 1ull)) : 0ull;
         const unsigned long long w = (lane < 2) ? all_lo : all_hi;
         lds_free[lane] = (unsigned int)((lane & 1) ? (w >> 32) : w);
     }
     __syncthreads();
     int last = -1;                                          // where the running path's most recent record lives: slot, 255 = scratch, -1 = none yet
     int deep_link[ZDR_MAX_RECORDED_DEPTH];
-#else
-    const int lds_vertices = (R.rr_depth < LV) ? max(R.rr_depth, 0) : LV;   // LDS records carry no RR fields
-#endif
     Counters cnt;
     ItemBanks ib; ib.logical[0] = ib.logical[1] = -1; ib.inflight[0] = ib.inflight[1] = 0;
     int bank = 1;
@@ -391,7 +373,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
     ps.smp = sampler_make<SK>(C, 0, 0, 0, 0);
     it.p = mk3(0.0f); it.uv.x = 0.0f; it.uv.y = 0.0f; it.ns = mk3(0.0f, 0.0f, 1.0f); it.ng = it.ns; it.inst = 0; it.prim = 0;
     int stall = 0;
-#ifdef ZDR_BWD_STATS
+#ifdef ZDR_MEASURE_STATS
     unsigned long long st_trips = 0, st_shaded = 0, st_fin = 0, st_iters = 0, st_steps = 0;
 #endif
     for (;;) {
@@ -412,14 +394,7 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                     w = decode_item(R, nxt);
                     perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
                     cam_mask = camera_mask(S, io, w);
-#if ZDR_BWD_LEAN_LDS
                     if (lane == 0) { lds_origin[bank * 2] = w.x; lds_origin[bank * 2 + 1] = w.y; }
-#else
-                    const f3 lg = load_le_grad(C, io, w);
-                    lds_perm[bank * WAVE + lane] = perm_seed;
-                    if (lane == 0) { lds_origin[bank * 2] = w.x; lds_origin[bank * 2 + 1] = w.y; }
-                    lds_leg[(bank * 3 + 0) * WAVE + lane] = lg.x; lds_leg[(bank * 3 + 1) * WAVE + lane] = lg.y; lds_leg[(bank * 3 + 2) * WAVE + lane] = lg.z;
-#endif
                     __syncthreads();
                     next_sample = w.s_begin; s_end = w.s_end;
                 }
@@ -427,24 +402,16 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                 continue;
             }
         }
-        const int took = primary_pop<SK>(S, C, !alive, lds_perm, lds_origin, pq, ps, it);
+        const int took = primary_pop<SK>(S, C, !alive, nullptr, lds_origin, pq, ps, it);
         if (took >= 0) {
-            const int bk = took >> 6, px = took & 63;
-#if ZDR_BWD_LEAN_LDS
-            (void)bk; (void)px;
             {   // the pixel's cotangent / spp, straight from the image (load_le_grad; a popped path is inside the shard)
                 const float4 gi = io.d_image[ps.smp.px + ps.smp.py * (uint32_t)R.width];
                 const float fs = (float)C.spp;
                 le_grad = mk3(__fdiv_rn(gi.x, fs), __fdiv_rn(gi.y, fs), __fdiv_rn(gi.z, fs));
                 if (any_nan(le_grad)) le_grad = mk3(0.0f);
             }
-#else
-            le_grad = mk3(lds_leg[(bk * 3 + 0) * WAVE + px], lds_leg[(bk * 3 + 1) * WAVE + px], lds_leg[(bk * 3 + 2) * WAVE + px]);
-#endif
             nrec = 0;
-#if ZDR_RECORD_POOL
             last = -1;
-#endif
             alive = true; pix = took;
         }
         if (__ballot(alive) != 0ull) {
@@ -456,50 +423,30 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
             PackedVertex plast;                             // the vertex shaded this trip, as recorded
             plast.a = plast.b = plast.c = plast.d = plast.e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             int sw_k = -1;                                  // next vertex the sweep consumes
-#if ZDR_RECORD_POOL
             bool want_store = false, mute = false;
-#endif
             SweepState sw; sw.A = mk3(0.0f); sw.Lv = mk3(0.0f); sw.s = 0.0f; sw.Z = 0.0f; sw.tw = 0.0f;
             if (alive) {
                 PathVertex pv; float term_plfrac = 0.0f;
                 Hit h;
                 done = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h, cnt);
-                plast = pack_vertex(pv, le_grad, R.prb_detached != 0);
-#if !ZDR_RECORD_POOL
-                if (nrec < lds_vertices) plast.e = make_float4(0.0f, 0.0f, 0.0f, plast.e.w);   // LDS records carry no RR fields
-#endif
+                plast = pack_vertex(pv, le_grad, R.prb_mode);
                 if (!done) { path_continue<A, false>(S, lds, ps, h, cnt); done = path_arrive<true, false, ENV>(S, ps, h, it, term_Li, cnt, &term_plfrac); }
                 // Only a vertex whose path goes on is put away: when the path ends here (52 % of the vertices) the sweep below starts
                 // from plast and nothing would read the record.  (5 LDS or scratch stores per vertex: 16.4 -> 15.5 ms for skipping
                 // the vertices that stop at the shading step alone.)
-#if ZDR_RECORD_POOL
-                want_store = !done && R.debug_no_scatter != 3;   // (ablation 3, no sweep: nothing is kept, so no slot leaks)
-#else
-                if (!done) {
-                    if (nrec < lds_vertices) {
-                        float4 *r = lds_rec + (nrec * 4) * WAVE + lane;
-                        r[0] = plast.a; r[WAVE] = plast.b; r[2 * WAVE] = plast.c; r[3 * WAVE] = plast.d;
-                        lds_dlnp[nrec * WAVE + lane] = plast.e.w;
-                    } else if (R.debug_no_scatter != 8) deep[nrec] = plast;   // ablation 8: not written either
-                }
-#endif
+                want_store = !done && ZDR_ABLATE != 3;      // (ablation 3, no sweep: nothing is kept, so no slot leaks)
                 nrec++;
                 if (done) {
                     alive = false;
-#if ZDR_RECORD_POOL
                     // a NaN path (prb.py:100: contributes nothing) is swept all the same, muted: the sweep is what returns its slots
-                    if (nrec > 0 && R.debug_no_scatter != 3) {
+                    if (nrec > 0 && ZDR_ABLATE != 3) {
                         mute = any_nan(ps.L);
-#else
-                    if (!any_nan(ps.L) && nrec > 0) {       // prb.py:100: NaN paths contribute nothing
-#endif
-                        sw_k = (R.debug_no_scatter == 3) ? -1 : nrec - 1;   // ablation 3: no sweep at all
+                        sw_k = nrec - 1;
                         sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f;
-                        sw.tw = R.prb_detached ? 0.0f : term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
+                        sw.tw = (R.prb_mode != ZDR_PRB_EXPECTATION) ? 0.0f : term_plfrac * dot(ps.beta, sw.A);   // emitter hit: d w_bsdf/dr = w_bsdf pl/(pb+pl) dln(pb)/dr
                     }
                 }
             }
-#if ZDR_RECORD_POOL
             // Reconverged: hand out slots, all requests of the trip at once.  Home slot first (slot == lane: conflict-free LDS access);
             // the lanes whose home is taken — a path's second and later records, or a home another lane borrowed — are ranked, the free
             // slots are ranked (a lane speaks for slot `lane`, then for slot 64 + lane), and request r takes free slot r: one
@@ -509,7 +456,10 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                 const unsigned long long req = __ballot(want_store);
                 int slot = -1;
                 if (req != 0ull) {
-                    const uint4 fw = *(const uint4 *)lds_free;                  // same address in every lane: a broadcast read
+                    // acquire: the ds_or of the previous trips' sweeps (any lane) are visible to this read
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const zdr_u4 fw = *(volatile const zdr_u4 *)lds_free;       // same address in every lane: a broadcast read
                     unsigned long long free_lo = ((unsigned long long)__builtin_amdgcn_readfirstlane(fw.y) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane(fw.x);
                     unsigned long long free_hi = ((unsigned long long)__builtin_amdgcn_readfirstlane(fw.w) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane(fw.z);
                     const bool home = want_store && lane < NS && ((free_lo >> lane) & 1ull) != 0ull;
@@ -538,7 +488,13 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                         if (mine && r2 >= 0 && r2 < cnt_lo) slot = pick_lo;
                         free_lo &= ~__ballot(fl && jl < nrest2);
                     }
-                    if (lane == 0) *(uint4 *)lds_free = make_uint4((unsigned int)free_lo, (unsigned int)(free_lo >> 32), (unsigned int)free_hi, (unsigned int)(free_hi >> 32));
+                    if (lane == 0) {
+                        const zdr_u4 nw = {(unsigned int)free_lo, (unsigned int)(free_lo >> 32), (unsigned int)free_hi, (unsigned int)(free_hi >> 32)};
+                        *(volatile zdr_u4 *)lds_free = nw;
+                    }
+                    // release: the new mask is in LDS before any lane's ds_or of the sweep below (in-order LDS, one wave)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
                 if (want_store) {
                     if (slot >= 0) {
@@ -552,20 +508,17 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                     }
                 }
             }
-#endif
             ib.inflight[0] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 0));
             ib.inflight[1] -= (uint32_t)__popcll(__ballot(done && (pix >> 6) == 1));
             // wave-uniform: sweep every finished path to its first vertex.  The sweep starts from the vertex packed this
             // trip (still in registers).
             PackedVertex cur = plast;
-#if ZDR_RECORD_POOL
             int loc = last;                                 // where the record of the sweep's next step lives
-#endif
-#ifdef ZDR_BWD_STATS   // measurement build (tools/bwd_stats.py): how full are the trips and the sweep iterations
+#ifdef ZDR_MEASURE_STATS   // measurement build (tools/bwd_stats.sh): how full are the trips and the sweep iterations
             st_trips++; st_shaded += (unsigned long long)__popcll(__ballot(alive || done));
             st_fin += (unsigned long long)__popcll(__ballot(sw_k >= 0));
 #endif
-            int sweep_cap = (R.debug_no_scatter == 4) ? 2 : ((R.debug_no_scatter == 5) ? 1 : 64);   // timing-only ablations 4 / 5: the sweep loop cut after 2 / 1 iterations
+            int sweep_cap = (ZDR_ABLATE == 4) ? 2 : ((ZDR_ABLATE == 5) ? 1 : 64);   // timing-only ablations 4 / 5: the sweep loop cut after 2 / 1 iterations
             // One step consumes `cur`, then fetches the record of the NEXT step into the same registers and only then queues the
             // gradient: the fetch (LDS, or scratch beyond the LDS records) is under way while the push runs, and no record is copied
             // (the loop runs 5.45 times per trip at 18 % of the lanes, profiles/r3_bwd_sweep_ablation.txt; fetching one step ahead
@@ -573,18 +526,17 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
             // with the sets swapping roles was slower still: profiles/r3_bwd_sweep_ablation.txt section 3).
             while (__ballot(sw_k >= 0) != 0ull && sweep_cap-- > 0) {
                 const bool swp = sw_k >= 0;
-#ifdef ZDR_BWD_STATS
+#ifdef ZDR_MEASURE_STATS
                 st_iters++; st_steps += (unsigned long long)__popcll(__ballot(swp));
 #endif
                 float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 f2 guv; guv.x = 0.0f; guv.y = 0.0f;
-                if (swp) { g = sweep_vertex(cur, sw, guv); sw_k--; }
+                if (swp) { g = sweep_vertex(cur, sw, guv, R.prb_mode); sw_k--; }
                 // everything that reads `cur` is finished here, before the fetch below overwrites it (left alone the compiler sinks
                 // part of the step below the fetch, loads into a second register set and copies — with a wait in front of the copies)
                 asm volatile("" : "+v"(g.x), "+v"(g.y), "+v"(g.z), "+v"(g.w), "+v"(guv.x), "+v"(guv.y), "+v"(sw.A.x), "+v"(sw.A.y), "+v"(sw.A.z),
                              "+v"(sw.Lv.x), "+v"(sw.Lv.y), "+v"(sw.Lv.z), "+v"(sw.s), "+v"(sw.Z), "+v"(sw.tw) : : "memory");
                 const bool fetch = swp && sw_k >= 0;
-#if ZDR_RECORD_POOL
                 const bool pooled = fetch && loc != 255;
                 int nloc = -1;
                 if (pooled) {
@@ -596,22 +548,11 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
                 // first to land — an LDS read is back in ~100 cycles, a scratch read in ~500 and behind the flush's atomics
                 asm volatile("" ::: "memory");
                 if (fetch && loc == 255) { cur = deep[sw_k]; nloc = deep_link[sw_k]; }
-                // the slots just read are free again (this wave's LDS operations execute in order: a later write cannot overtake the read)
-                if (pooled) atomicOr(&lds_free[loc >> 5], 1u << (loc & 31));
+                // the slots just read are free again: a wavefront-scope RELEASE or, so the reads of the record above are ordered before it
+                // (and this wave's LDS operations execute in order anyway: a later write cannot overtake the read)
+                if (pooled) __hip_atomic_fetch_or(&lds_free[loc >> 5], 1u << (loc & 31), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (fetch) loc = nloc;
-                scatter_push(q, io.cells, swp && !mute && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
-#else
-                if (fetch && sw_k < lds_vertices) {
-                    const float4 *r = lds_rec + (sw_k * 4) * WAVE + lane;
-                    cur.a = r[0]; cur.b = r[WAVE]; cur.c = r[2 * WAVE]; cur.d = r[3 * WAVE];
-                    cur.e = make_float4(0.0f, 0.0f, 0.0f, lds_dlnp[sw_k * WAVE + lane]);
-                }
-                // LDS first: both kinds of fetch write the same registers (for different lanes), and the second kind waits for the
-                // first to land — an LDS read is back in ~100 cycles, a scratch read in ~500
-                asm volatile("" ::: "memory");
-                if (fetch && sw_k >= lds_vertices && R.debug_no_scatter != 7 && R.debug_no_scatter != 8) cur = deep[sw_k];   // ablations 7 / 8: deep records not read back (wrong gradients; what records out of scratch could save at most)
-                scatter_push(q, io.cells, swp && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, R.debug_no_scatter);   // prb.py:178-187
-#endif
+                scatter_push(q, io.cells, swp && !mute && any_nonzero4(g) && !any_nan4(g), guv, g, R.tex_h, R.tex_w, ZDR_ABLATE);   // prb.py:178-187
             }
         }
 #pragma unroll
@@ -621,20 +562,25 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(DScene S_, R
         stall = progress ? 0 : stall + 1;
         if (stall > 4) { raise_device_error(S, ZDR_DEVERR_STALL); break; }   // cannot happen (every branch above makes progress); never spin on the GPU, never end silently
     }
-    scatter_finish(q, io.cells, R.tex_h, R.tex_w, R.debug_no_scatter);
-#ifdef ZDR_BWD_STATS
+    scatter_finish(q, io.cells, R.tex_h, R.tex_w, ZDR_ABLATE);
+    {   // every path has been swept, so every slot must be back: a leaked or doubly allocated slot is a protocol error, said aloud
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const zdr_u4 fw = *(volatile const zdr_u4 *)lds_free;
+        const bool whole = fw.x == (unsigned int)all_lo && fw.y == (unsigned int)(all_lo >> 32) && fw.z == (unsigned int)all_hi && fw.w == (unsigned int)(all_hi >> 32);
+        if (!whole && lane == 0 && stall <= 4 && ZDR_ABLATE == 0) raise_device_error(S, ZDR_DEVERR_POOL);
+    }
+#ifdef ZDR_MEASURE_STATS
     if (lane == 0) {
         atomicAdd(io.counters + 0, st_trips); atomicAdd(io.counters + 1, st_shaded); atomicAdd(io.counters + 2, st_fin);
         atomicAdd(io.counters + 3, st_iters); atomicAdd(io.counters + 4, st_steps);
         atomicAdd(io.counters + 5, q.st_flushes); atomicAdd(io.counters + 6, q.st_entries); atomicAdd(io.counters + 7, q.st_dups);
     }
 #endif
-#if ZDR_KARG_RELOAD
 #undef S
 #undef R
 #undef C
 #undef io
-#endif
 }
 
 // ---------------------------------------------------------------------- direct / collocated
@@ -643,17 +589,14 @@ template <int INTEG, int SK, class A, bool BWD, bool STATS, bool ENV>
 #define ZDR_MIN_WAVES_DIRECT 4   // brute-force direct kernels, cbox 512^2 spp 64: 153 VGPRs (3 waves per SIMD) 1.175 / 1.331 ms, 128 VGPRs (6 spilled) 1.110 / 1.267 ms
 #endif
 // (the environment instantiations take 170 VGPRs: bounded to 3 waves per SIMD, which costs no spill, instead of the 2 the compiler settles for)
-__global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV ? 3 : ZDR_MIN_WAVES_DIRECT) : 1) void k_simple(DScene S_, RenderCfg R_, SamplerCfg C_, KernelIO io_) {
+__global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV ? 3 : ZDR_MIN_WAVES_DIRECT) : 1) void k_simple(ZDR_PATH_KERNEL_PARAMS) {
     ZDR_KARGS_BEGIN
-#if ZDR_KARG_RELOAD
 #define S (ka->S)
 #define R (ka->R)
 #define C (ka->C)
 #define io (ka->io)
-#endif
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
     __shared__ __attribute__((aligned(16))) float lds_q[BWD ? ZDR_SCATTER_LDS_FLOATS : 4];
-    A::prepare(S, lds);
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     Counters cnt;
@@ -678,17 +621,15 @@ __global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV
             else rad = direct_sample<SK, A, BWD, STATS, ENV>(S, R, C, io, lds, smp, o, d, cam_mask, le_grad, cnt, guv, grad);
             if (!any_nan(rad)) sum = sum + clamp_radiance(rad); else COUNT(C_NAN);
         }
-        if (BWD) scatter_push(q, io.cells, w.valid && any_nonzero4(grad) && !any_nan4(grad), guv, grad, R.tex_h, R.tex_w, R.debug_no_scatter);
+        if (BWD) scatter_push(q, io.cells, w.valid && any_nonzero4(grad) && !any_nan4(grad), guv, grad, R.tex_h, R.tex_w, ZDR_ABLATE);
     }
-    if (BWD) scatter_finish(q, io.cells, R.tex_h, R.tex_w, R.debug_no_scatter);
+    if (BWD) scatter_finish(q, io.cells, R.tex_h, R.tex_w, ZDR_ABLATE);
     if (!BWD && !STATS) store_pixel(R, C, io, w, sum);
     flush_counters<STATS>(io, cnt);
-#if ZDR_KARG_RELOAD
 #undef S
 #undef R
 #undef C
 #undef io
-#endif
 }
 
 // Folds the staging cells into the gradient texture: texel (x, y) receives corner (dx, dy) of every
@@ -732,7 +673,6 @@ __global__ void k_cells_to_grad(const float4 *__restrict__ cells, float4 *__rest
 template <int SK, class A>
 __global__ __launch_bounds__(WAVE) void k_uvgrad(DScene S, RenderCfg R, SamplerCfg C, KernelIO io) {
     extern __shared__ int lds[];
-    A::prepare(S, lds);
     const WorkItem w = decode_block(R);
     const uint32_t perm_seed = (SK == 0) ? xxhash32_4((uint32_t)w.x, (uint32_t)w.y, C.seed, 0u) : 0u;
     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -794,13 +734,7 @@ int zdr_launch_zero(void *p, size_t bytes, hipStream_t st) {
 // dynamic LDS of a wave that traverses the BVH: the first entries of the per-lane stacks (accel.h).  Sets S.lds_stack.
 static size_t bvh_dyn_lds(DScene &S, bool backward) {
     S.lds_stack = std::min<int>(S.stack_entries, backward ? ZDR_BVH_LDS_STACK_BWD : ZDR_BVH_LDS_STACK);
-    int top = 0;
-#ifdef ZDR_BVH_TOP_CACHE                                                            // experiment (scene.h): measured slower, compiled out by default
-    top = backward ? ZDR_BVH_LDS_TOP_BWD : ZDR_BVH_LDS_TOP;
-    if (const char *e = getenv("ZDR_BVH_LDS_TOP")) top = std::max(0, atoi(e));      // measurement knob (both passes)
-#endif
-    S.lds_top = std::min<int>(S.nnodes, std::min(top, 256));
-    return (size_t)S.lds_stack * WAVE * sizeof(int) + (size_t)S.lds_top * 64;       // the stack (a multiple of 256 B), then the top nodes
+    return (size_t)S.lds_stack * WAVE * sizeof(int);
 }
 // Persistent grid of the path kernels: as many single-wave workgroups as the chip holds at once (never more
 // than there are items).  A workgroup that is not resident at first simply starts later and draws what is left.
@@ -903,7 +837,6 @@ int zdr_launch_render(const DScene &S_in, const RenderCfg &R, const SamplerCfg &
 template <class A, bool ANY>
 __global__ __launch_bounds__(WAVE) void k_trace(DScene S, const float4 *rays, uint32_t n, int32_t *out_i, float *out_f) {
     extern __shared__ int lds[];        // BvhAccel: traversal stacks (sized at launch); unused otherwise
-    A::prepare(S, lds);
     uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     bool valid = i < n;
     float4 a = valid ? rays[2 * (size_t)i] : make_float4(0, 0, 0, 0), b = valid ? rays[2 * (size_t)i + 1] : make_float4(0, 0, 1, 0);
@@ -950,7 +883,6 @@ int zdr_launch_trace(const DScene &S_in, int accel_is_bvh, int any, const float 
 template <int SK, class A, bool ENV>
 __global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, SamplerCfg C, KernelIO io, const int32_t *queries, uint32_t n, int maxv, float *out) {
     extern __shared__ int lds[];
-    A::prepare(S, lds);                                     // by the whole wave, before any lane leaves
     const uint32_t i = blockIdx.x * WAVE + threadIdx.x;
     if (i >= n) return;                                     // no wave-level operation below: lanes are independent
     const int stride = 8 + 24 * maxv;
@@ -983,7 +915,7 @@ __global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, Sampl
         const int slot = h.slot;
         term_Li = mk3(0.0f); plfrac = 0.0f;
         bool stop = path_shade<SK, A, true, false, ENV>(S, R, C, io, lds, ps, it, pv, h2, cnt);
-        recs[nv] = pack_vertex(pv, le_grad, R.prb_detached != 0);
+        recs[nv] = pack_vertex(pv, le_grad, R.prb_mode);
         if (nv < maxv) {
             float *q = o + 8 + 24 * nv;
             const int went_on = pv.c != 0.0f ? 1 : 0;       // the BSDF sample was kept (prb.py:73-87 passed)
@@ -999,9 +931,9 @@ __global__ __launch_bounds__(WAVE) void k_path_dump(DScene S, RenderCfg R, Sampl
     }
     o[0] = __int_as_float(nv); o[1] = ps.L.x; o[2] = ps.L.y; o[3] = ps.L.z; o[5] = term_Li.x; o[6] = term_Li.y; o[7] = term_Li.z;
     if (!any_nan(ps.L) && nv > 0) {                         // prb.py:100; the sweep of k_path_bwd
-        SweepState sw; sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f; sw.tw = R.prb_detached ? 0.0f : plfrac * dot(ps.beta, sw.A);
+        SweepState sw; sw.A = le_grad * term_Li; sw.Lv = sw.A; sw.s = 0.0f; sw.Z = 0.0f; sw.tw = (R.prb_mode != ZDR_PRB_EXPECTATION) ? 0.0f : plfrac * dot(ps.beta, sw.A);
         for (int k = nv - 1; k >= 0; k--) {
-            f2 guv; const float4 g = sweep_vertex(recs[k], sw, guv);
+            f2 guv; const float4 g = sweep_vertex(recs[k], sw, guv, R.prb_mode);
             if (k < maxv) { float *q = o + 8 + 24 * k; q[12] = g.x; q[13] = g.y; q[14] = g.z; q[15] = g.w; }
         }
     }
@@ -1043,10 +975,45 @@ __global__ void k_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n, int n
     for (; k < stride; k++) o[k] = 0.0f;
 }
 
-int zdr_launch_sampler_dump(const SamplerCfg &C, const int32_t *queries, uint32_t n, int32_t nvert, int32_t rr_depth, float *out, hipStream_t st) {
+// The same numbers drawn THE WAY THE PATH KERNELS DRAW THEM (shade_ctx / sample_bsdf, integrators.h): the pixel's next2f, then per
+// vertex all seven numbers at once through cmj_vertex_samples (two Kensler permutations per register) and the roulette draw through
+// cmj_next_with_index — whenever cmj_can_batch(C), which is every BASELINE configuration — else the calls one by one.
+template <int SK>
+__global__ void k_vertex_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n, int nvert, int rr_depth, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t px = (uint32_t)q[3 * i], py = (uint32_t)q[3 * i + 1], idx = (uint32_t)q[3 * i + 2];
+    uint32_t perm_seed = (SK == 0) ? xxhash32_4(px, py, C.seed, 0u) : 0u;
+    Sampler s = sampler_make<SK>(C, px, py, perm_seed, idx);
+    const int stride = 2 + 8 * nvert;
+    float *o = out + (size_t)i * stride;
+    int k = 0;
+    f2 u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+    const bool pre = (SK == 0) && cmj_can_batch(C);             // shade_ctx's x.pre (without an environment light)
+    for (int v = 0; v < nvert; v++) {
+        if (pre) {
+            const VertexSamples vs = cmj_vertex_samples(C, s);
+            o[k++] = vs.u_pick; o[k++] = vs.u_prim; o[k++] = vs.u_pt.x; o[k++] = vs.u_pt.y; o[k++] = vs.u_lobe; o[k++] = vs.u_dir.x; o[k++] = vs.u_dir.y;
+            if (v >= rr_depth) o[k++] = cmj_next_with_index(C, s, vs.i_rr);
+        } else {
+            o[k++] = sampler_next<SK>(C, s); o[k++] = sampler_next<SK>(C, s);
+            u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+            o[k++] = sampler_next<SK>(C, s);
+            u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+            if (v >= rr_depth) o[k++] = sampler_next<SK>(C, s);
+        }
+    }
+    for (; k < stride; k++) o[k] = 0.0f;
+}
+
+int zdr_launch_sampler_dump(const SamplerCfg &C, const int32_t *queries, uint32_t n, int32_t nvert, int32_t rr_depth, float *out, int as_path_kernels, int *batched, hipStream_t st) {
+    if (batched) *batched = (as_path_kernels && C.kind == ZDR_SAMPLER_CMJ && cmj_can_batch(C)) ? 1 : 0;
     if (n == 0) return 0;
     dim3 grid((n + 63) / 64);
-    if (C.kind == ZDR_SAMPLER_CMJ) hipLaunchKernelGGL(k_sampler_dump<0>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
+    if (as_path_kernels) {
+        if (C.kind == ZDR_SAMPLER_CMJ) hipLaunchKernelGGL(k_vertex_sampler_dump<0>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
+        else hipLaunchKernelGGL(k_vertex_sampler_dump<1>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
+    } else if (C.kind == ZDR_SAMPLER_CMJ) hipLaunchKernelGGL(k_sampler_dump<0>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
     else hipLaunchKernelGGL(k_sampler_dump<1>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -53,7 +53,7 @@ class Scene:
         self.sampler = sampler
         self.max_depth = MAX_DEPTH
         self.rr_depth = RR_DEPTH
-        self.prb_mode = "expectation"      # or "detached": the reference's constant-roulette / constant-MIS adjoint (include/zdr.h)
+        self.prb_mode = "expectation"      # or "detached": the reference's constant-roulette / constant-MIS adjoint; "literal": with the BSDF-sample seed of prb.py:162 as written (include/zdr.h)
         self.env_count = 0
         self._handle = None
         self.load_geometry(models, accel=accel)
@@ -252,6 +252,15 @@ class Scene:
         out = torch.empty((q.shape[0], 2 + 8 * nvert), dtype=torch.float32, device=self.device)
         N.check(N.lib().zdr_sampler_dump(self._handle, N.SAMPLERS[self.sampler], int(seed) & 0xFFFFFFFF, int(spp), q.data_ptr(), q.shape[0], nvert, rr_depth, out.data_ptr(), self._stream()))
         return out
+
+    def vertex_sampler_dump(self, queries, spp, seed=0, nvert=3, rr_depth=RR_DEPTH):
+        """As sampler_dump, but drawn the way the path kernels draw (include/zdr.h, zdr_vertex_sampler_dump).
+        Returns (draws, batched): batched is True when the packed two-permutations-per-register route ran."""
+        q = queries.reshape(-1, 3).to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty((q.shape[0], 2 + 8 * nvert), dtype=torch.float32, device=self.device)
+        b = C.c_int32(-1)
+        N.check(N.lib().zdr_vertex_sampler_dump(self._handle, N.SAMPLERS[self.sampler], int(seed) & 0xFFFFFFFF, int(spp), q.data_ptr(), q.shape[0], nvert, rr_depth, out.data_ptr(), C.byref(b), self._stream()))
+        return out, bool(b.value)
 
     def path_dump(self, material, queries, res, spp, seed, *, d_image=None, maxv=16):
         """Per-path traces (include/zdr.h, zdr_path_dump): queries (n, 3) int32 cuda {px, py, sample_index} ->

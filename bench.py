@@ -159,6 +159,33 @@ def fd_summary():
     return out or None
 
 
+def shard_union_check(scene, renderer, material, rank, world, W=256, spp=16, seed=12345):
+    """An N-rank run checks itself BEFORE its timed loop: one small frame rendered sharded over the ranks (tiles dealt round-robin,
+    one all_reduce of the image and one of the gradient — the run's own exchange) and, on rank 0, once more unsharded on its GPU
+    alone.  The two must be the same image (bit for bit in `tiles` mode when both cut the sample range into the same chunks,
+    which at this size they do) and the same gradient up to the order the float atomics land in: the line then says whether
+    RCCL summed the right tensors, not only how fast.  Collective calls: every rank must take part."""
+    import torch
+    res = (W, W)
+    m = material.detach().clone().requires_grad_()
+    cot = torch.rand((W, W, 4), device=material.device, generator=torch.Generator(device=material.device).manual_seed(7)) + 0.5
+    img = renderer.render(m, res=res, spp=spp, seed=seed)
+    (img * cot).sum().backward()
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    m1 = material.detach().clone().requires_grad_()
+    ref = scene.render(m1, res=res, spp=spp, seed=seed)
+    (ref * cot).sum().backward()
+    torch.cuda.synchronize()
+    g, gref = m.grad.double(), m1.grad.double()
+    return {"workload": f"path {W}x{W} spp={spp}, {world} ranks ({renderer.mode}) vs rank 0 alone",
+            "image_max_abs": float((img.detach() - ref.detach()).abs().max()), "image_bit_identical": bool(torch.equal(img.detach(), ref.detach())),
+            "image_mean": float(ref.detach()[..., :3].mean()),
+            "grad_rel_l1": float((g - gref).abs().sum() / gref.abs().sum().clamp_min(1e-30)),
+            "grad_nnz": [int((g != 0).sum()), int((gref != 0).sum())]}
+
+
 class Leg:
     """One timed workload: `steps` steps of render + backward on one scene, HIP events around the native calls."""
 
@@ -319,6 +346,7 @@ def main():
     mat_np = scenes.cbox_material_np()
     material = torch.from_numpy(mat_np).to(dev).requires_grad_()
     renderer = zd.attach(scene, mode=args.shard)
+    union = shard_union_check(scene, renderer, material, rank, world) if (world > 1 and integrator == "path" and args.shard != "seeds") else None
     leg = Leg(scene, material, W, spp, renderer, world)
     dt_rank = leg.run(args.steps, args.warmup)
     dt = dt_rank
@@ -364,6 +392,8 @@ def main():
                                   "note": "per step; step = wall clock of the timed loop / steps on each rank, kernels = HIP events around the native calls"}
             out["allreduce_ms"] = {"image": col(3), "gradient": col(4), "bytes": {"image": W * W * 16, "gradient": int(material.numel()) * 4},
                                    "note": "per step, HIP events on the compute stream around torch.distributed.all_reduce (includes waiting for the slowest rank)"}
+        if union is not None:
+            out["shard_union_check"] = union
         fd = fd_summary()
         if fd: out["grad_rel_err_vs_fd"] = fd
         if world == 1 and cfg == "c3" and not (args.res or args.spp) and not args.no_extra_configs:

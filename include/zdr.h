@@ -13,6 +13,16 @@
  * reference scene is not re-entrant either) — the handle owns per-call workspaces (staging cells, chunk
  * partials, work counters, the parked-vertex FIFOs), so two renders of ONE scene must not overlap, not even on
  * different streams: enqueue them on one stream, or use one scene handle per stream.
+ *
+ * Stream capture (hipStreamBeginCapture / torch.cuda.graph).  The render calls only enqueue, so a call made while its stream is
+ * capturing is recorded into the graph — provided one eager call of the same kind, resolution and spp has sized the handle's
+ * workspaces before (a call that would have to allocate while capturing returns ZDR_E_UNSUPPORTED).  A graph names the handle's
+ * workspaces and everything of the scene at capture time (camera, lights, environment, sampler tables, seed are frozen into the
+ * kernel arguments).  From the first captured call on the handle therefore (a) never frees a device buffer before
+ * zdr_scene_destroy — one that must grow is replaced and the old one kept alive for the graphs that name it — and (b) rebuilds
+ * the camera-ray tile masks in every call, captured or eager, because a replay rewrites them for its own view.  Eager calls of
+ * any view or size and any number of captures may thus be interleaved with replays on the handle's stream; what still holds is
+ * the rule above: one call (or replay) in flight per handle.  Destroy the graphs before the handle.
  */
 #ifndef ZDR_H
 #define ZDR_H

@@ -65,15 +65,18 @@ def test_forward_and_backward_match_the_oracle(material, million):
     rt = Trace(S.path_dump(oracle_params(scene, W, H, spp, seed + 1, mat.shape[:2]), mat, q, d_image=cot))
     st = deviation_percentiles(tr, rt)
     print(f"[paths] 1M triangles material {material}: {st}")
+    # flipped paths are bounded by the ruler used everywhere else (gpu_util.Flips.check_count): max(5, 2 x what the oracle's own
+    # IEEE and FMA builds differ by) — a hit next to a shared edge of the 6 mm triangles reports the neighbour in either build
+    # (measured: 42 against the ruler's 33 of 73,728 on the rough material)
+    fma_b = Trace(Sf.path_dump(oracle_params(scene, W, H, spp, seed + 1, mat.shape[:2]), mat, q, d_image=cot))
+    fl = deviation_percentiles(fma_b, rt)
+    print(f"[paths] 1M triangles material {material}, oracle fma vs ieee: {fl}")
+    assert st["flipped"] <= max(5, 2 * fl["flipped"]), (st, fl)
     if material == "A":
-        assert st["flipped"] <= 2.6e-3 * n, st                   # round 2's bar (6 of 2,304 paths); measured: 42 of 73,728 — a hit next to a shared edge of the 6 mm triangles reports the neighbour
         assert st["L"][50] <= 2e-6 and st["grad"][50] <= 2e-6 and st["L"][99] <= 1e-3 and st["grad"][99] <= 1e-3, st
     else:
         # glossy bounces over 6 mm triangles: a direction that differs in the fifth digit lands on the neighbouring
         # triangle, which counts as another decision — calibrate with the oracle's own IEEE / FMA builds
-        fl = deviation_percentiles(Trace(Sf.path_dump(oracle_params(scene, W, H, spp, seed + 1, mat.shape[:2]), mat, q, d_image=cot)), rt)
-        print(f"[paths] 1M triangles material {material}, oracle fma vs ieee: {fl}")
-        assert st["flipped"] <= 2 * fl["flipped"] + 5, (st, fl)
         for key in ("L", "grad"):
             assert st[key][50] <= max(2e-5, 2 * fl[key][50]) and st[key][90] <= max(1e-3, 2 * fl[key][90]), (key, st, fl)
     # the kernels' gradient texture is the scatter of the traced vertex gradients
@@ -84,7 +87,6 @@ def test_forward_and_backward_match_the_oracle(material, million):
     # set aside (their pixels / texel footprints), everything else meets the bars — for the glossy material the bars
     # calibrated by the oracle's own FMA build, as everywhere (gpu_util.assert_image_parity).
     pb = oracle_params(scene, W, H, spp, seed + 1, mat.shape[:2])
-    fma_b = Trace(Sf.path_dump(pb, mat, q, d_image=cot))
     fb = Flips(scene, S, Sf, mat, (W, H), spp, seed + 1, cot=cot, what=f"1M triangles backward {material}", traces=(tr, rt, fma_b))
     ff = Flips(scene, S, Sf, mat, (W, H), spp, seed, what=f"1M triangles forward {material}")
     pf = oracle_params(scene, W, H, spp, seed, mat.shape[:2])

@@ -335,9 +335,9 @@ ZD bool sample_bsdf(const RenderCfg &R, const SamplerCfg &C, const ShadeCtx &x, 
             // expectation then depends on q(material); the sweep differentiates through it (sweep_vertex).
             pv.rr = rr_kind;
             if (rr_kind == 2) pv.bnorm = ps.beta;
-            // ZDR_PRB_LITERAL (prb.py:157-163): no roulette fields; bnorm carries beta f / pdf, the part of the literal seed
+            // ZDR_PRB_LITERAL (prb.py:157-163): the roulette fields go unused; bnorm carries beta f / pdf, the part of the literal seed
             // beta / pdf * Le that is not already in Q and in the arriving radiance (sweep_vertex)
-            if (R.prb_mode == ZDR_PRB_LITERAL) { pv.rr = 0; pv.bnorm = beta_in * (f * inv_p); }
+            if (R.prb_mode == ZDR_PRB_LITERAL) pv.bnorm = beta_in * (f * inv_p);   // (pv.rr keeps the roulette kind for zdr_path_dump's flags; pack_vertex ignores it in this mode)
         }
     }
     ps.depth++;

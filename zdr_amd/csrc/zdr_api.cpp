@@ -418,8 +418,26 @@ struct zdr_scene {
     unsigned long long *d_counters = nullptr;
     unsigned int *d_error = nullptr;                        // device error word (scene.h, ZDR_DEVERR_*), sticky until read
     uint64_t device_bytes = 0;
+    // A render call recorded while its stream was CAPTURING (hipStreamBeginCapture; torch.cuda.graph) bakes this handle's workspace
+    // pointers into a graph that may be replayed at any later time.  From then on the handle never frees a buffer a kernel can read or
+    // write — one that has to grow is retired (kept until zdr_scene_destroy) and replaced — and never trusts the tile masks in the
+    // buffer, which a replay rebuilds for ITS view behind the host's back (render_common).
+    bool captured = false;
+    std::vector<void *> retired;
     DScene ds{};
 };
+
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+// frees a buffer of the handle that no kernel in flight reads — unless a captured graph may still name it
+static void release_buffer(zdr_scene *s, void *p) {
+    if (!p) return;
+    if (s->captured) s->retired.push_back(p); else (void)hipFree(p);
+}
 
 template <class T>
 static hipError_t upload(T **dst, const void *src, size_t bytes, uint64_t *acc) {
@@ -452,7 +470,7 @@ static int upload_light_table(zdr_scene *s, const std::vector<int32_t> &lights, 
     if (tab.empty()) tab.push_back(make_float4(0, 0, 0, 0));
     if (tab.size() > s->light_tris_cap) {
         HIPCHK(hipStreamSynchronize(st));
-        (void)hipFree(s->d_light_tris); s->d_light_tris = nullptr; s->light_tris_cap = 0;
+        release_buffer(s, s->d_light_tris); s->d_light_tris = nullptr; s->light_tris_cap = 0;
         HIPCHK(hipMalloc((void **)&s->d_light_tris, tab.size() * sizeof(float4)));
         s->light_tris_cap = tab.size();
     }
@@ -662,6 +680,7 @@ extern "C" int zdr_scene_destroy(zdr_scene *s) {
     (void)hipSetDevice(s->device);
     if (!s->isect_in_nodes) (void)hipFree(s->d_isect); (void)hipFree(s->d_pairs); (void)hipFree(s->d_ppairs); (void)hipFree(s->d_shade); (void)hipFree(s->d_nodes); (void)hipFree(s->d_emission); (void)hipFree(s->d_light_insts); (void)hipFree(s->d_light_tris); (void)hipFree(s->d_light_range); (void)hipFree(s->d_emission4);
     (void)hipFree(s->d_inst_tri_begin); (void)hipFree(s->d_slot_of_tri); (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf); (void)hipFree(s->d_partial); (void)hipFree(s->d_ring); (void)hipFree(s->d_work_counters); (void)hipFree(s->d_tile_masks); (void)hipFree(s->d_cells); (void)hipFree(s->d_counters); (void)hipFree(s->d_error);
+    for (void *p : s->retired) (void)hipFree(p);
     delete s;
     return ZDR_OK;
 }
@@ -694,7 +713,7 @@ extern "C" int zdr_scene_set_envmap(zdr_scene *s, const float *tex, uint32_t tex
     if (!s) return fail(ZDR_E_INVALID, "null scene");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());     // nothing in flight may still read the old tables
-    (void)hipFree(s->d_env_tex); (void)hipFree(s->d_alias_prob); (void)hipFree(s->d_alias_idx); (void)hipFree(s->d_env_pdf);
+    release_buffer(s, s->d_env_tex); release_buffer(s, s->d_alias_prob); release_buffer(s, s->d_alias_idx); release_buffer(s, s->d_env_pdf);
     s->d_env_tex = nullptr; s->d_alias_prob = nullptr; s->d_alias_idx = nullptr; s->d_env_pdf = nullptr;
     s->ds.env_count = 0; s->ds.env_tex = nullptr; s->ds.alias_prob = nullptr; s->ds.alias_idx = nullptr; s->ds.env_pdf = nullptr;
     if (!tex) return ZDR_OK;
@@ -720,7 +739,7 @@ extern "C" int zdr_scene_set_pmj02bn_tables(zdr_scene *s, const uint32_t *pmj, u
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());     // nothing in flight may still read the old tables
     // only the sampler tables belong to this setter (the environment buffers are zdr_scene_set_envmap's)
-    (void)hipFree(s->d_pmj); (void)hipFree(s->d_bn); s->d_pmj = nullptr; s->d_bn = nullptr;
+    release_buffer(s, s->d_pmj); release_buffer(s, s->d_bn); s->d_pmj = nullptr; s->d_bn = nullptr;
     memset(&s->tab, 0, sizeof s->tab);
     HIPCHK(upload(&s->d_pmj, pmj, (size_t)nsets * nsamples * 2 * sizeof(uint32_t), &s->device_bytes));
     HIPCHK(upload(&s->d_bn, bn, (size_t)ntex * bnres * bnres * sizeof(uint16_t), &s->device_bytes));
@@ -825,11 +844,19 @@ static int make_render_cfg(const zdr_render_params *p, bool backward, RenderCfg 
     return ZDR_OK;
 }
 
-static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
+// A workspace that has to grow: not while the stream is capturing (an allocation cannot be recorded, and the capture would name a
+// buffer that does not exist yet) — one eager call of the same kind and size beforehand sizes everything.
+static int may_allocate(bool capturing, const char *what) {
+    if (!capturing) return ZDR_OK;
+    return fail(ZDR_E_UNSUPPORTED, std::string("the ") + what + " workspace would have to be allocated while the stream is capturing: make one eager call of this kind, resolution and spp on the handle first");
+}
+
+static int ensure_partial(zdr_scene *s, const RenderCfg &R, bool capturing) {
     if (R.nchunks <= 1) return ZDR_OK;
     size_t need = (size_t)R.nchunks * (size_t)R.ntiles * 64 * sizeof(float4);   // [chunk][tile of the shard][lane]
     if (need > s->partial_bytes) {
-        (void)hipFree(s->d_partial); s->d_partial = nullptr; s->partial_bytes = 0;
+        if (int rc = may_allocate(capturing, "chunk-partial")) return rc;
+        release_buffer(s, s->d_partial); s->d_partial = nullptr; s->partial_bytes = 0;
         HIPCHK(hipMalloc((void **)&s->d_partial, need));
         s->partial_bytes = need;
     }
@@ -838,22 +865,24 @@ static int ensure_partial(zdr_scene *s, const RenderCfg &R) {
 
 // Workspace of the path kernels: one FIFO of ZDR_RING_CAP x 64 parked camera-ray vertices (two float4 each,
 // 32 KiB) per persistent workgroup, and the eight item counters the workgroups draw from (zeroed per launch).
-static int ensure_ring(zdr_scene *s, hipStream_t st) {
+static int ensure_ring(zdr_scene *s, hipStream_t st, bool capturing) {
     size_t need = (size_t)ZDR_MAX_PERSISTENT_BLOCKS * ZDR_RING_CAP * 2 * 64 * sizeof(float4);
     if (need > s->ring_bytes) {
-        (void)hipFree(s->d_ring); s->d_ring = nullptr; s->ring_bytes = 0;
+        if (int rc = may_allocate(capturing, "parked-vertex FIFO")) return rc;
+        release_buffer(s, s->d_ring); s->d_ring = nullptr; s->ring_bytes = 0;
         HIPCHK(hipMalloc((void **)&s->d_ring, need));
         s->ring_bytes = need;
     }
-    if (!s->d_work_counters) HIPCHK(hipMalloc((void **)&s->d_work_counters, 8 * sizeof(unsigned int)));
+    if (!s->d_work_counters) { if (int rc = may_allocate(capturing, "work-counter")) return rc; HIPCHK(hipMalloc((void **)&s->d_work_counters, 8 * sizeof(unsigned int))); }
     if (zdr_launch_zero(s->d_work_counters, 8 * sizeof(unsigned int), st)) return fail(ZDR_E_HIP, "zero-fill launch failed");
     return ZDR_OK;
 }
 
-static int ensure_cells(zdr_scene *s, const RenderCfg &R, hipStream_t st) {
+static int ensure_cells(zdr_scene *s, const RenderCfg &R, hipStream_t st, bool capturing) {
     size_t need = (size_t)R.cell_copies * (size_t)(R.tex_h + 1) * (R.tex_w + 1) * 16 * sizeof(float);
     if (need > s->cells_bytes) {
-        (void)hipFree(s->d_cells); s->d_cells = nullptr; s->cells_bytes = 0;
+        if (int rc = may_allocate(capturing, "staging-cell")) return rc;
+        release_buffer(s, s->d_cells); s->d_cells = nullptr; s->cells_bytes = 0;
         HIPCHK(hipMalloc((void **)&s->d_cells, need));
         s->cells_bytes = need;
     }
@@ -891,11 +920,13 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     RenderCfg R; SamplerCfg C;
     rc = make_render_cfg(p, backward != 0, R); if (rc) return rc;
     rc = make_sampler_cfg(s, p->sampler, p->seed, p->spp, C); if (rc) return rc;
-    if (backward) { rc = ensure_cells(s, R, (hipStream_t)stream); if (rc) return rc; }
-    else if (!stats) { rc = ensure_partial(s, R); if (rc) return rc; }
+    const bool capturing = stream_is_capturing((hipStream_t)stream);
+    if (capturing) s->captured = true;                  // sticky: a graph may name this handle's buffers from now on (zdr_scene)
+    if (backward) { rc = ensure_cells(s, R, (hipStream_t)stream, capturing); if (rc) return rc; }
+    else if (!stats) { rc = ensure_partial(s, R, capturing); if (rc) return rc; }
     if (p->integrator == ZDR_PATH) {
         if (p->spp > (1u << 25)) return fail(ZDR_E_UNSUPPORTED, "path integrator: spp above 2^25");   // queue entries pack pixel << 26 | bank << 25 | sample
-        rc = ensure_ring(s, (hipStream_t)stream); if (rc) return rc;
+        rc = ensure_ring(s, (hipStream_t)stream, capturing); if (rc) return rc;
     }
     KernelIO io; memset(&io, 0, sizeof io);
     io.ring = s->d_ring; io.work_counters = s->d_work_counters;
@@ -904,7 +935,8 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (masks) {
         size_t need = (size_t)R.tiles_x * R.tiles_y * sizeof(unsigned long long);
         if (need > s->tile_mask_bytes) {
-            (void)hipFree(s->d_tile_masks); s->d_tile_masks = nullptr; s->tile_mask_bytes = 0; s->tile_mask_key_set = false;
+            if (int rc2 = may_allocate(capturing, "tile-mask")) return rc2;
+            release_buffer(s, s->d_tile_masks); s->d_tile_masks = nullptr; s->tile_mask_bytes = 0; s->tile_mask_key_set = false;
             HIPCHK(hipMalloc((void **)&s->d_tile_masks, need));
             s->tile_mask_bytes = need;
         }
@@ -915,6 +947,9 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
                          R.cam_o[0], R.cam_o[1], R.cam_o[2], R.cam_fwd[0], R.cam_fwd[1], R.cam_fwd[2], R.cam_right[0], R.cam_right[1], R.cam_right[2],
                          R.cam_upp[0], R.cam_upp[1], R.cam_upp[2], (float)R.tiles_x, (float)R.tiles_y};
         io.tile_masks_valid = (s->tile_mask_key_set && memcmp(key, s->tile_mask_key, sizeof key) == 0) ? 1 : 0;
+        // A captured call must carry its own k_tile_masks (a replay may follow an eager render of another view on this handle), and
+        // once a graph exists its replays rewrite the buffer unseen by the host: the key is never trusted again.
+        if (s->captured) io.tile_masks_valid = 0;
         // the key is recorded only when k_tile_masks is really going to run: a shard that owns no tile (more shards than
         // tiles) launches nothing, and must not leave the key of masks nobody built behind for the next call
         if ((long)R.ntiles * R.nchunks > 0) { memcpy(s->tile_mask_key, key, sizeof key); s->tile_mask_key_set = true; }
@@ -931,7 +966,7 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (zdr_launch_render(s->ds, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
         return fail(ZDR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(hipGetLastError()));
     static const bool check_every_call = getenv("ZDR_CHECK") && atoi(getenv("ZDR_CHECK")) != 0;   // opt-in: costs a synchronise per call
-    if (check_every_call && !stats) return check_device_error(s, (hipStream_t)stream);
+    if (check_every_call && !stats && !capturing) return check_device_error(s, (hipStream_t)stream);   // (a synchronise cannot be captured: zdr_scene_check after the replay instead)
     return ZDR_OK;
 }
 

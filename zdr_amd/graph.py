@@ -10,9 +10,13 @@ kernels themselves (tests/test_zz_gpu_graph.py::test_captured_render_matches_eag
         image, d_material = step(cotangent)         # reads `material` and `cotangent` in place, returns static tensors
         ...                                         # update material in place (e.g. an optimiser step on the same storage)
 
-Kernel arguments are frozen at capture — the seed among them: every replay renders the same sample set (a fixed-seed
-objective; capture again for another seed).  Not under ZDR_CHECK=1, which synchronises inside every call.  One capture per scene handle may be replayed at a time (include/zdr.h: one call in
-flight per handle).
+Kernel arguments are frozen at capture — the seed, the camera, the lights and the environment among them: every replay renders the
+same view with the same sample set (a fixed-seed objective; capture again for another seed or view).  Under ZDR_CHECK=1 the per-call
+device check is skipped for the captured calls (a synchronise cannot be recorded); call scene.check() after a replay instead.
+Eager renders of OTHER views or sizes and further captures may be interleaved with replays on the same scene: from its first captured
+call on, a scene handle keeps every workspace a graph may name alive until it is destroyed and rebuilds the camera-ray tile masks in
+every call (include/zdr.h, "Stream capture"; tests/test_zz_gpu_graph.py::test_a_replay_survives_eager_renders_of_other_views).  What
+still holds is include/zdr.h's rule of one call — or replay — in flight per handle: keep them on one stream.
 """
 from __future__ import annotations
 

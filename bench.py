@@ -109,9 +109,12 @@ def pmc_record(kernel, workload_key):
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         return None, False
-    if d.get("workload_key", "c3") != workload_key or kernel not in d:
+    stale = d.get("csrc_sha256") != hip_build.source_hash()
+    if workload_key != d.get("workload_key", "c3"):          # the other workloads of the file sit under their own key ("c5")
+        d = d.get(workload_key) or {}
+    if kernel not in d:
         return None, False
-    return d[kernel], d.get("csrc_sha256") != hip_build.source_hash()
+    return d[kernel], stale
 
 
 def cpu_baseline(scene, mat_np, W, spp_sample):
@@ -138,24 +141,33 @@ def cpu_baseline(scene, mat_np, W, spp_sample):
 
 
 def fd_summary():
-    """Gradient accuracy against finite differences, measured by tools/fd_validate.py / tools/fd_directional.py."""
+    """Gradient accuracy against finite differences, measured by tools/fd_validate.py / tools/fd_directional.py.  Every file says
+    which kernel sources it was measured on (csrc_sha256 = zdr_amd.build.source_hash()): a figure from other sources than this
+    tree's — or from a file of an earlier round that carries no hash — is printed with "fd_stale": true, never silently."""
+    from zdr_amd import build as hip_build
+    here = hip_build.source_hash()
     out = {}
-    for key, name in (("fd_validate_procedure_diffuse_texel", "fd_validate_diffuse_texel"), ("fd_validate_procedure_roughness_texel", "fd_validate_roughness_texel")):
-        for rnd in ("r3", "r2", "r1"):
+    def load(name, key):
+        for rnd in ("r4", "r3", "r2", "r1"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")
             try:
-                t = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")))["tail"]
-                out[key] = {"rel_err": t["rel_err"], "one_sigma": t["one_sigma"], "spp": t["spp"], "seeds": t["seeds"], "source": f"profiles/{rnd}_{name}.json"}
-                break
+                d = json.load(open(path))
+                return d, d[key], f"profiles/{rnd}_{name}.json", d.get("csrc_sha256") != here
             except Exception:
                 continue
-    for rnd in ("r3", "r2", "r1"):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_fd_directional.json")))["result"]
-            out["whole_image_directional"] = {k: {"rel_err": v["rel_err"], "one_sigma": v["one_sigma"]} for k, v in d.items()}
-            out["whole_image_directional"]["source"] = f"profiles/{rnd}_fd_directional.json"
-            break
-        except Exception:
-            continue
+        return None
+    for key, name in (("fd_validate_procedure_diffuse_texel", "fd_validate_diffuse_texel"), ("fd_validate_procedure_roughness_texel", "fd_validate_roughness_texel")):
+        r = load(name, "tail")
+        if r:
+            _, t, src, stale = r
+            out[key] = {"rel_err": t["rel_err"], "one_sigma": t["one_sigma"], "spp": t["spp"], "seeds": t["seeds"], "source": src, "fd_stale": stale}
+    r = load("fd_directional", "result")
+    if r:
+        _, d, src, stale = r
+        out["whole_image_directional"] = {k: {"rel_err": v["rel_err"], "one_sigma": v["one_sigma"]} for k, v in d.items()}
+        out["whole_image_directional"].update({"source": src, "fd_stale": stale})
+    if out:
+        out["fd_stale"] = any(v.get("fd_stale", False) for v in out.values() if isinstance(v, dict))
     return out or None
 
 
@@ -312,6 +324,18 @@ def extra_config(name, cfg_key, dev, mat_np, steps, warmup):
            "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms", "fwd_achieved", "fwd_frac")}}
     if accel == "bvh":
         out["triangles"] = scene.info()["ntris"]
+    if integrator == "path":   # counter traffic of this leg's dominant kernel (tools/refresh_profiles.sh), when it was measured on these sources
+        rec, stale = pmc_record("k_path_bwd", cfg_key)
+        if rec is not None:
+            ok = not stale and rec.get("traffic_bytes") is not None
+            out["roofline"]["traffic"] = rec["traffic_bytes"] if ok else None
+            out["roofline"]["traffic_stale"] = bool(stale)
+            if ok:
+                alg = roof["bytes_per_sample"]["bwd"] * n
+                out["roofline"]["algorithmic_bytes_per_launch"] = round(alg)
+                out["roofline"]["traffic_over_algorithmic"] = round(rec["traffic_bytes"] / alg, 3)
+                for k in ("l2_hit_rate", "valu_issue_frac", "valu_lane_utilisation", "wait_any_frac"):
+                    if rec.get(k) is not None: out["roofline"][k] = round(rec[k], 4)
     scene.render_forward = scene.render_backward = None     # break the cycle scene -> timing wrapper -> leg -> scene
     del leg, scene, material
     gc.collect()

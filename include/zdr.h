@@ -210,9 +210,18 @@ int zdr_path_dump(zdr_scene *scene, const zdr_render_params *params, const float
  * planar convex quads the walk merged out of coplanar triangle pairs — slots 2q and 2q + 1 for q < Q, the other
  * triangles after them — and the records of a quad's two triangles start at the corner OPPOSITE the shared edge;
  * *stack_entries receives how many of the quads are parallelograms (they come first; the walk tests them in pairs with
- * the first triangle's u, v and 1 - u, 1 - v) (tests/test_brute_quads.py). */
+ * the first triangle's u, v and 1 - u, 1 - v) (tests/test_brute_quads.py).  (zdr_scene_create additionally orders the
+ * primitives WITHIN each of these groups so that those a shadow segment can meet come first — zdr_debug_never_occluders —
+ * which needs the lights and is not reproduced here.) */
 int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int accel, float *nodes_out, uint32_t nodes_cap,
                           uint32_t *nnodes, uint32_t *stack_entries, int32_t *order_out, float *isect_out);
+
+/* Host-only: which triangles can never lie between a surface point of the scene and a point of a light, i.e. can be left out of
+ * the shadow-segment walk of next-event estimation (prb.py:57-59; csrc/zdr_api.cpp, never_occluders: the triangle's plane supports
+ * the whole scene and the lights keep a distance from it that makes a hit inside (tmin, tmax) impossible).  The brute-force accel
+ * skips the pairs of the pair walk whose primitives all qualify.  tri_xyz: ntris x 9 world-space corners; is_light_tri: ntris flags;
+ * never_out: ntris flags (tests/test_brute_quads.py). */
+int zdr_debug_never_occluders(const float *tri_xyz, uint32_t ntris, const uint8_t *is_light_tri, uint8_t *never_out);
 
 #ifdef __cplusplus
 }

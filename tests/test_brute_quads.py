@@ -138,3 +138,69 @@ def test_quad_walk_emulation_matches_the_oracle(cbox_arrays, cbox_oracle):
     both = (tri >= 0) & (tri == ref)
     terr = np.abs(t[both] - rbt[both, 2]) / (1e-5 * np.abs(rbt[both, 2]) + 5e-6)
     assert both.mean() > 0.3 and (terr > 1).mean() < 2e-4 and terr.max() < 50
+
+
+# ---- the shadow walk's pair mask: which triangles can never lie between a surface point and a point of a light
+
+def never_occluders(tris, is_light):
+    tri = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    light = np.ascontiguousarray(is_light, np.uint8)
+    out = np.zeros(tri.shape[0], np.uint8)
+    rc = _native.lib().zdr_debug_never_occluders(tri.ctypes.data, tri.shape[0], light.ctypes.data, out.ctypes.data)
+    assert rc == 0, _native.lib().zdr_last_error()
+    return out.astype(bool)
+
+
+def test_the_walls_of_the_cornell_box_never_occlude_a_shadow_segment(cbox_arrays):
+    """Back wall, floor, left and right wall (8 triangles) support the scene from outside and the ceiling light keeps > 2 units from
+    them: no segment from a surface point to a point of the light can meet them inside (1e-4, 0.9999 dist).  The CEILING does not
+    qualify: the light hangs 7 mm below it, too close to rule out a hit by rounding alone — it stays in the walk, like the box
+    faces and the light itself.  3 of the 9 pairs of the pair walk drop out of every shadow walk."""
+    import oracle
+    from zdr_amd import geometry
+    A = cbox_arrays
+    tris = A.verts[A.tris][:, :, :3].astype(np.float32)           # identity transforms: object space = world space
+    is_light = np.zeros(32, bool); is_light[A.inst_tri_begin[1]:A.inst_tri_begin[2]] = True
+    never = never_occluders(tris, is_light)
+    assert never.sum() == 8 and not never[is_light].any()
+    ylo = tris[..., 1].min(axis=1); yhi = tris[..., 1].max(axis=1)
+    ceiling = (ylo > 5.3) & ~is_light
+    assert ceiling.sum() == 2 and not never[ceiling].any()
+    # the claim itself, by brute force: 200,000 shadow segments from points on EVERY triangle of the scene to points on the light,
+    # traced by the oracle against a scene made of the flagged triangles alone: none is occluded
+    rng = np.random.default_rng(0)
+    n = 200000
+    def points(idx):
+        u = rng.random((n, 2)).astype(np.float32); f = u.sum(1) > 1; u[f] = 1 - u[f]
+        T = tris[idx]
+        return T[:, 0] + u[:, :1] * (T[:, 1] - T[:, 0]) + u[:, 1:] * (T[:, 2] - T[:, 0])
+    p = points(rng.integers(0, 32, n)); q = points(rng.choice(np.nonzero(is_light)[0], n))
+    # a fifth of the origins exactly ON an edge or corner of their triangle (where a wall meets the floor: the closest a ray gets)
+    p[: n // 5] = tris[rng.integers(0, 32, n // 5), rng.integers(0, 3, n // 5)]
+    d = q - p; dist = np.linalg.norm(d, axis=1).astype(np.float32)
+    ok = dist > 1e-3
+    rays = np.zeros((n, 8), np.float32); rays[:, :3] = p; rays[:, 3] = 1e-4; rays[:, 4:7] = d / np.maximum(dist, 1e-30)[:, None]; rays[:, 7] = np.float32(0.9999) * dist
+    nv = tris[never].reshape(-1, 3)
+    verts8 = np.zeros((nv.shape[0], 8), np.float32); verts8[:, :3] = nv; verts8[:, 7] = 1
+    S = oracle.OracleScene.from_arrays(geometry.from_arrays(verts8, np.arange(nv.shape[0], dtype=np.int32).reshape(-1, 3)))
+    occ = S.trace_any(rays[ok])
+    assert occ.sum() == 0, int(occ.sum())
+
+
+def test_never_occluder_classification_is_conservative():
+    """No lights: nothing is ruled out.  A wall with the light ON its far side is an occluder; a light too close to a supporting
+    plane (the bound on a rounding-induced hit exceeds half of tmin) keeps that plane in the walk; a plane that cuts the scene
+    is never ruled out."""
+    floor = quad((0, 0, 0), (4, 0, 0), (4, 0, 4), (0, 0, 4))
+    lamp = quad((1.5, 3, 1.5), (2.5, 3, 1.5), (2.5, 3, 2.5), (1.5, 3, 2.5))
+    screen = quad((0, 1, 2), (4, 1, 2), (4, 2, 2), (0, 2, 2))    # a vertical panel in the middle of the floor: geometry on both sides
+    low_lamp = quad((1.5, 0.001, 1.5), (2.5, 0.001, 1.5), (2.5, 0.001, 2.5), (1.5, 0.001, 2.5))
+    t = np.array(floor + lamp + screen, np.float32)
+    light = np.array([0, 0, 1, 1, 0, 0], bool)
+    assert never_occluders(t, light).tolist() == [True, True, False, False, False, False]
+    assert not never_occluders(t, np.zeros(6, bool)).any()
+    t2 = np.array(floor + low_lamp, np.float32)
+    assert not never_occluders(t2, np.array([0, 0, 1, 1], bool)).any()      # 1 mm above the floor: too close to call
+    below = quad((1.5, -3, 1.5), (2.5, -3, 1.5), (2.5, -3, 2.5), (1.5, -3, 2.5))
+    t3 = np.array(floor + lamp + below, np.float32)               # lights on BOTH sides of the floor
+    assert not never_occluders(t3, np.array([0, 0, 1, 1, 1, 1], bool))[:2].any()

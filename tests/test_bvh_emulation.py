@@ -80,6 +80,11 @@ def traverse(nodes, isect, o, d, tmin, tmax, any_hit):
     with np.errstate(divide="ignore"):
         inv = np.float32(1.0) / d
     stack = []
+    # a child word is the byte offset of what it names — nodes (64 bytes each) first, the plane records (48 bytes per slot) behind them — | its count
+    isect_off = 64 * nnodes
+    def where(word):
+        off, c = word & ~15, word & 7
+        return (off // 64 if c == 0 else (off - isect_off) // 48), c
     nid, cnt = 0, (ntris if nnodes == 0 else 0)
     budget = 2 * (nnodes + ntris) + 8
     steps = 0
@@ -93,7 +98,9 @@ def traverse(nodes, isect, o, d, tmin, tmax, any_hit):
             origin, scale, q, p = decode_node(nodes[nid])
             with np.errstate(invalid="ignore", over="ignore"):
                 A = (scale * inv).astype(np.float32); B = ((origin - o) * inv).astype(np.float32)
-            e = [qbox_entry(c, q, A, B, tmin, best_t, inv) if (p[c] & 7) != 7 else 3.0e38 for c in range(4)]
+            e = [qbox_entry(c, q, A, B, tmin, best_t, inv) for c in range(4)]      # unused slots carry an inverted box: no test for them
+            if np.isfinite(o).all() and np.isfinite(d).all():              # (a ray of NaNs / infinities decides no comparison: it may "enter" one, and its walk ends there)
+                assert all(e[c] > 2.0e38 for c in range(4) if (p[c] & 7) == 7), (o, d)
             em = min(e)
             if em < 2.0e38:
                 nxt, taken = -1, [False] * 4
@@ -105,7 +112,7 @@ def traverse(nodes, isect, o, d, tmin, tmax, any_hit):
                     if not taken[c] and e[c] < 2.0e38:
                         stack.append(p[c])
                 if nxt >= 0:
-                    nid, cnt = nxt >> 3, nxt & 7
+                    nid, cnt = where(nxt)
                     descended = True
         else:
             for s in range(nid, nid + cnt):
@@ -119,7 +126,9 @@ def traverse(nodes, isect, o, d, tmin, tmax, any_hit):
         if not stack:
             break
         e = stack.pop()
-        nid, cnt = e >> 3, e & 7
+        nid, cnt = where(e)
+        if cnt == 7:                                   # only a ray of NaNs gets into an unused slot: its walk ends, it hits nothing
+            break
     return slot, best_t, steps
 
 
@@ -209,8 +218,8 @@ def test_the_top_of_the_tree_is_numbered_breadth_first():
             expect += 1
             child = nodes[nid].view(np.uint32)[12:16]
             for cw in child:
-                if (cw & 7) == 0:
-                    assert (cw >> 3) > nid
-                    nxt.append(int(cw >> 3))
+                if (cw & 7) == 0:                                # a node: the word is its byte offset, 64 bytes per node
+                    assert (cw >> 6) > nid
+                    nxt.append(int(cw >> 6))
         frontier, level = nxt, level + 1
     assert level >= 4

@@ -227,6 +227,48 @@ def test_tile_masks_cull_nothing_that_can_be_hit(integrator, mat_a, monkeypatch)
             if k == 0: assert float(img[..., :3].sum()) > 0.0
 
 
+@pytest.mark.parametrize("integrator", ["path", "direct"])
+def test_shadow_pair_mask_changes_no_answer(integrator, mat_a, mat_b, monkeypatch):
+    """The shadow walk of the brute-force accel skips the pairs whose primitives can never lie between a surface point and a point
+    of a light (zdr_api.cpp never_occluders: 3 of the Cornell box's 9 pairs — back wall, floor, side walls).  Same answers, bit for
+    bit: images equal, per-path traces (every vertex's light-sample decision, radiance and gradient) equal, gradient textures equal
+    up to the order of the float atomics — for the stock lights, after update_lights has made a box a second light, and for a camera
+    inside the box.  ZDR_NO_SHADOW_MASK=1 (read when the lights are set) keeps every pair in the walk."""
+    from path_trace import all_queries
+    def scenes():
+        monkeypatch.delenv("ZDR_NO_SHADOW_MASK", raising=False)
+        a = make_scene(integrator, accel="brute")
+        monkeypatch.setenv("ZDR_NO_SHADOW_MASK", "1")
+        b = make_scene(integrator, accel="brute")
+        monkeypatch.delenv("ZDR_NO_SHADOW_MASK", raising=False)
+        return a, b
+    W, H, spp = 72, 56, 8
+    cot = torch.rand((H, W, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) + 0.5
+    for case, mat in (("stock", mat_a), ("glossy", mat_b), ("inside", mat_b)):
+        m = torch.from_numpy(mat).cuda()
+        a, b = scenes()
+        if case == "inside":
+            for sc in (a, b): sc.camera = Camera(fov=1.9, origin=float3(0.3, 1.2, -1.0), target=float3(-0.4, 2.0, -4.0), up=float3(0.2, 1.0, 0.1))
+        for seed in (1, 2):
+            ia, ib = a.render_forward(m, (W, H), spp, seed), b.render_forward(m, (W, H), spp, seed)
+            assert torch.equal(ia, ib), (case, seed)
+            ga, gb = torch.zeros_like(m), torch.zeros_like(m)
+            a.render_backward(cot, ga, m, (W, H), spp, seed); b.render_backward(cot, gb, m, (W, H), spp, seed)
+            torch.testing.assert_close(ga, gb, rtol=1e-4, atol=1e-6 * float(gb.abs().max()))   # float atomics: same terms, free order
+            if integrator == "path":
+                q = torch.from_numpy(all_queries(W, H, spp)).cuda()
+                assert torch.equal(a.path_dump(m, q, (W, H), spp, seed + 1, d_image=cot).view(torch.int32), b.path_dump(m, q, (W, H), spp, seed + 1, d_image=cot).view(torch.int32)), (case, seed)
+        assert float(ia[..., :3].sum()) > 0.0
+    # another set of lights: the room itself (instance 0) glows as well -> the mask is rebuilt with the lights (every plane now carries a light: nothing is ruled out)
+    m = torch.from_numpy(mat_a).cuda()
+    monkeypatch.delenv("ZDR_NO_SHADOW_MASK", raising=False)
+    a = make_scene(integrator, accel="brute"); a.update_lights([float3(2.0, 1.0, 0.5), float3(17, 12, 4)])
+    monkeypatch.setenv("ZDR_NO_SHADOW_MASK", "1")
+    b = make_scene(integrator, accel="brute"); b.update_lights([float3(2.0, 1.0, 0.5), float3(17, 12, 4)])
+    monkeypatch.delenv("ZDR_NO_SHADOW_MASK", raising=False)
+    assert torch.equal(a.render_forward(m, (W, H), spp, 5), b.render_forward(m, (W, H), spp, 5))
+
+
 @pytest.mark.parametrize("W,H,spp,max_depth,rr_depth", [
     (1, 1, 1, 16, 2),        # one pixel, one sample: a wave with one valid lane and a one-entry FIFO
     (5, 3, 3, 16, 2),        # fewer camera samples than one refill batch

@@ -205,24 +205,6 @@ struct BruteAccel {
         brute_resolve(S, h, prim, o, d);
         return h;
     }
-    // The shadow segment of next-event estimation (prb.py:59, direct.py:44): only the pairs of S.shadow_pairs can lie between a
-    // surface point and a point of a light (the host proves it for the others: zdr_api.cpp, never_occluders); the mask is
-    // wave-uniform, the walk over its set bits scalar code.  Same answer as any(), bit for bit.
-    ZD static bool any_shadow(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
-        bool occ = false;
-        unsigned long long m = S.shadow_pairs;
-        const int npairs = (S.nquads + 1) >> 1;
-        if (npairs < 64) m &= (1ull << npairs) - 1ull;
-        if (S.ntris > 128) return any(S, nullptr, o, d, tmin, tmax);   // more pairs than mask bits
-#pragma unroll 1
-        while (m) {
-            const int k = __builtin_ctzll(m);
-            m &= m - 1ull;
-            const PairHit ph = pair_test_k(S, k, o, d);
-            occ |= ((ph.t.x > tmin) & (ph.t.x < tmax) & (ph.c.x >= 0.0f)) | ((ph.t.y > tmin) & (ph.t.y < tmax) & (ph.c.y >= 0.0f));
-        }
-        return occ;
-    }
     ZD static bool any(const DScene &S, int *, f3 o, f3 d, float tmin, float tmax) {
         bool occ = false;
         auto take = [&](const PairHit &ph) {
@@ -269,8 +251,8 @@ struct BvhAccel {
     // stack: this wave's LDS region, min(S.stack_entries, ZDR_BVH_LDS_STACK) x 64 ints; entry e of lane l at stack[e * 64 + l].
     // A work item is (id, cnt): cnt == 0 -> node id, 1..4 -> leaf slots [id, id + cnt); 7 marks an unused child and is never pushed.
     struct Walker {                  // one ray in flight on this lane
-        f3 o, d, inv; float tmin; Hit h;          // h.slot while walking: the hit triangle's record as a 16-byte offset from S.walk_base (slot_of), -1 = none
-        int sp; uint32_t off; int cnt, budget;    // what the ray stands on: byte offset from S.walk_base of a node (cnt == 0) or of a leaf's first plane record (cnt 1..2); 7 = an unused child slot
+        f3 o, d, inv; float tmin; Hit h;
+        int sp, id, cnt, budget;
     };
     ZD static int root_count(const DScene &S) { return (S.nnodes == 0) ? S.ntris : 0; }
     // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it impossible for a wave to
@@ -279,10 +261,8 @@ struct BvhAccel {
     ZD static void start(const DScene &S, Walker &w, f3 o, f3 d, float tmin, float tmax) {
         w.o = o; w.d = d; w.tmin = tmin; w.inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         w.h.slot = -1; w.h.u = 0.0f; w.h.v = 0.0f; w.h.t = tmax;
-        w.sp = 0; w.off = (S.nnodes == 0) ? S.isect_off : 0u; w.cnt = root_count(S); w.budget = walk_budget(S);
+        w.sp = 0; w.id = 0; w.cnt = root_count(S); w.budget = walk_budget(S);
     }
-    // the slot of the triangle whose plane record starts `units` 16-byte units behind S.walk_base (records are 48 bytes)
-    ZD static int slot_of(const DScene &S, int units) { return (int)(__umulhi((uint32_t)units - (S.isect_off >> 4), 0xAAAAAAABu) >> 1); }
     // One visit (a node or a leaf) and the pop that follows it, in two halves: fetch() issues the loads of whatever the
     // ray stands on, consume() uses them and returns true while the ray has more to visit.
     // ONE memory round trip per trip of the wave.  The walk is latency-bound (waves sit in s_waitcnt 2/3 of the time):
@@ -298,16 +278,13 @@ struct BvhAccel {
     // the triangle array instead — any valid address — and consume() looks at `dead` before anything else), n4 / n5 are written only
     // for a leaf of more than one triangle, which is exactly when consume() reads them.  Zero-filling the 24 registers cost 23 v_mov in
     // EVERY trip of the walk (a frozen undef is materialised as a zero too): 7 % of its instructions.
-    // Nodes and plane records live in one allocation (zdr_api.cpp) and a child word IS the byte offset of what it names (| its count
-    // in the low bits: offsets are multiples of 16): the fetch address costs one AND — no branch between "node" and "triangle", no
-    // multiply by the record size (that was a four-pass v_mad_u64_u32 in every trip).
-    // An unused child slot carries an inverted box that no ray with a finite direction can enter, so the node branch does not test
-    // for it; should a ray of NaNs be sent into one all the same (every comparison of its slab test is undecided), the walk ends
-    // here: such a ray hits nothing.
     ZD static Fetched fetch(const DScene &S, int *stack, Walker &w) {
         Fetched f;
-        f.dead = (--w.budget < 0) | (w.cnt == 7);
-        const uint32_t off = f.dead ? S.isect_off : w.off;      // (a dead lane reads the first records of the triangle array: >= 2 records = 6 float4 are always there)
+        f.dead = (--w.budget < 0);
+        // nodes and plane records live in one allocation (zdr_api.cpp): scalar base + 32-bit byte offset (a node is 64 bytes, a triangle 48) —
+        // three VALU instead of a branch, a four-pass v_mad_i64 and 64-bit shifts and adds in every trip
+        uint32_t off = (w.cnt == 0) ? ((uint32_t)w.id << 6) : (uint32_t)w.id * 48u + S.isect_off;
+        if (f.dead) off = S.isect_off;                         // >= 2 records = 6 float4 are always there
         const float4 *p = (const float4 *)(S.walk_base + off);
         f.n0 = p[0]; f.n1 = p[1]; f.n2 = p[2]; f.n3 = p[3];
         if (w.cnt > 1) { f.n4 = p[4]; f.n5 = p[5]; }
@@ -317,7 +294,7 @@ struct BvhAccel {
         const int lane = threadIdx.x & 63;
         bool ray_done = f.dead;
         const f3 o = w.o, d = w.d, inv = w.inv; const float tmin = w.tmin;
-        const int cnt = w.cnt;
+        const int id = w.id, cnt = w.cnt;
         const float4 n0 = f.n0, n1 = f.n1, n2 = f.n2, n3 = f.n3;
         if (!ray_done && cnt == 0) {
             // slab distances on the node's quantisation grid: t = (origin + scale q - o) / d = q A + B
@@ -325,29 +302,33 @@ struct BvhAccel {
             const f3 B = mk3((n0.x - o.x) * inv.x, (n0.y - o.y) * inv.y, (n0.z - o.z) * inv.z);
             const uint32_t lxq = __float_as_uint(n1.z), lyq = __float_as_uint(n1.w), lzq = __float_as_uint(n2.x);
             const uint32_t hxq = __float_as_uint(n2.y), hyq = __float_as_uint(n2.z), hzq = __float_as_uint(n2.w);
+            const uint32_t c0 = __float_as_uint(n3.x), c1 = __float_as_uint(n3.y), c2 = __float_as_uint(n3.z), c3 = __float_as_uint(n3.w);
             // the planes the ray enters / leaves through, for the four children at once
             const bool ngx = inv.x < 0.0f, ngy = inv.y < 0.0f, ngz = inv.z < 0.0f;
             const uint32_t nxq = ngx ? hxq : lxq, fxq = ngx ? lxq : hxq, nyq = ngy ? hyq : lyq, fyq = ngy ? lyq : hyq, nzq = ngz ? hzq : lzq, fzq = ngz ? lzq : hzq;
-            const float e0 = qbox_entry<0>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
-            const float e1 = qbox_entry<1>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
-            const float e2 = qbox_entry<2>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
-            const float e3 = qbox_entry<3>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
-            const int p0 = __float_as_int(n3.x), p1 = __float_as_int(n3.y), p2 = __float_as_int(n3.z), p3 = __float_as_int(n3.w);
+            float e0 = qbox_entry<0>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
+            float e1 = qbox_entry<1>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
+            float e2 = qbox_entry<2>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
+            float e3 = qbox_entry<3>(nxq, nyq, nzq, fxq, fyq, fzq, A, B, tmin, w.h.t);
+            // count == 7 marks an unused child slot (a slab test cannot express "never hit" for a ray full of NaNs): selects, not branches
+            e0 = ((c0 & 7u) != 7u) ? e0 : 3.0e38f; e1 = ((c1 & 7u) != 7u) ? e1 : 3.0e38f;
+            e2 = ((c2 & 7u) != 7u) ? e2 : 3.0e38f; e3 = ((c3 & 7u) != 7u) ? e3 : 3.0e38f;
+            int p0 = (int)c0, p1 = (int)c1, p2 = (int)c2, p3 = (int)c3;
             // nearest child: visit now; the other hit children go on the stack.  On the fast path the four
             // stack writes are unconditional (LDS stores are cheap, branches are not): a slot is kept only
             // if sp advances past it.
-            const float em = fminf(fminf(e0, e1), fminf(e2, e3));
+            float em = fminf(fminf(e0, e1), fminf(e2, e3));
             if (em < 2.0e38f) {
-                const bool t0 = (e0 == em), t1 = !t0 & (e1 == em), t2 = !(t0 | t1) & (e2 == em), t3 = !(t0 | t1 | t2);
-                const int next = t0 ? p0 : (t1 ? p1 : (t2 ? p2 : p3));
+                bool t0 = (e0 == em), t1 = !t0 & (e1 == em), t2 = !(t0 | t1) & (e2 == em), t3 = !(t0 | t1 | t2);
+                int next = t0 ? p0 : (t1 ? p1 : (t2 ? p2 : p3));
                 int sp = w.sp;
                 if (sp + 4 <= LN) {
-                    int at = sp * 64 + lane;                 // (an index, not a pointer: the pointer form compiled to 64-bit arithmetic)
-                    stack[at] = p0; at += (!t0 & (e0 < 2.0e38f)) ? 64 : 0;
-                    stack[at] = p1; at += (!t1 & (e1 < 2.0e38f)) ? 64 : 0;
-                    stack[at] = p2; at += (!t2 & (e2 < 2.0e38f)) ? 64 : 0;
-                    stack[at] = p3; at += (!t3 & (e3 < 2.0e38f)) ? 64 : 0;
-                    sp = (at - lane) >> 6;
+                    int *sl = stack + sp * 64 + lane;
+                    sl[0] = p0; sl += (!t0 & (e0 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p1; sl += (!t1 & (e1 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p2; sl += (!t2 & (e2 < 2.0e38f)) ? 64 : 0;
+                    sl[0] = p3; sl += (!t3 & (e3 < 2.0e38f)) ? 64 : 0;
+                    sp = (int)((sl - (stack + lane)) >> 6);
                 } else {                                // near or past the LDS part: one entry at a time
                     const int pp[4] = {p0, p1, p2, p3};
                     const bool keep[4] = {!t0 && e0 < 2.0e38f, !t1 && e1 < 2.0e38f, !t2 && e2 < 2.0e38f, !t3 && e3 < 2.0e38f};
@@ -359,19 +340,16 @@ struct BvhAccel {
                         }
                     }
                 }
-                w.sp = sp; w.off = (uint32_t)next & ~15u; w.cnt = next & 7;
+                w.sp = sp; w.id = next >> 3; w.cnt = next & 7;
                 return true;
             }
         } else if (!ray_done) {
-            const int units = (int)(w.off >> 4);
             float t;
-            if (tri_test(n0, n1, n2, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = units; }
-            if (cnt > 1 && tri_test(n3, f.n4, f.n5, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = units + 3; }
+            if (tri_test(n0, n1, n2, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id; }
+            if (cnt > 1 && tri_test(n3, f.n4, f.n5, o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = id + 1; }
 #if ZDR_BVH_LEAF > 2
-            for (int s = 2; s < cnt; s++) {               // leaves of more than two triangles
-                const float4 *q = (const float4 *)(S.walk_base + w.off) + 3 * s;
-                if (tri_test(q[0], q[1], q[2], o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = units + 3 * s; }
-            }
+            for (int s = id + 2; s < id + cnt; s++)       // leaves of more than two triangles
+                if (tri_test(S.isect[3 * (size_t)s], S.isect[3 * (size_t)s + 1], S.isect[3 * (size_t)s + 2], o, d, tmin, w.h.t, t)) { w.h.t = t; w.h.slot = s; }
 #endif
             if (anyhit && w.h.slot >= 0) ray_done = true;         // any-hit: the first hit settles it
         }
@@ -383,7 +361,7 @@ struct BvhAccel {
             typedef __attribute__((address_space(3))) int lds_int_t;      // an explicit LDS pointer: ds_read_b32, whatever the optimiser thinks of the scratch access next to it
             int e = ((lds_int_t *)stack)[((w.sp < LN) ? w.sp : 0) * 64 + lane];
             if (w.sp >= LN) e = deep[w.sp - LN];
-            w.off = (uint32_t)e & ~15u; w.cnt = e & 7;
+            w.id = e >> 3; w.cnt = e & 7;
             return true;
         }
         return false;
@@ -423,7 +401,7 @@ struct BvhAccel {
                 }
             }
         }
-        if (HAS_B && needB) { hit = w.h; if (hit.slot >= 0) hit.slot = slot_of(S, hit.slot); hit_barycentrics(S, hit, oB, dB); }
+        if (HAS_B && needB) { hit = w.h; hit_barycentrics(S, hit, oB, dB); }
     }
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         bool occ; Hit h;
@@ -435,7 +413,6 @@ struct BvhAccel {
         walk<true, false>(S, stack, o, d, tmin, tmax, false, o, d, tmin, tmax, occ, h);
         return occ;
     }
-    ZD static bool any_shadow(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) { return any(S, stack, o, d, tmin, tmax); }
     // need1: the lane has a shadow ray (o1, d1) at all; need2: it has a continuation ray (o2, d2)
     ZD static void shadow_and_closest(const DScene &S, int *stack, bool need1, f3 o1, f3 d1, float tmin1, float tmax1, bool need2, f3 o2, f3 d2, bool &occ, Hit &h) {
         walk<true, true>(S, stack, o1, d1, tmin1, tmax1, need2, o2, d2, 0.0f, 1e30f, occ, h, need1);

@@ -214,67 +214,16 @@ static void find_quads(const std::vector<h3> &pos, uint32_t ntris, std::vector<i
     std::sort(quads.begin(), quads.end(), [](const QuadPair &x, const QuadPair &y) { return x.par != y.par ? x.par : x.a < y.a; });
 }
 
-// Which triangles can NEVER lie between a surface point of the scene and a point of a light — the shadow segments of next-event
-// estimation (prb.py:57-59, direct.py:42-44), traced with tmin = 1e-4 and tmax = 0.9999 dist.  A triangle W qualifies when its plane
-// SUPPORTS the scene: every vertex of every triangle lies on one side of it (or on it, up to `viol`, the worst violation found)
-// and every vertex of every light triangle lies on that side by at least b.  A segment from p (signed distance a >= -viol, as the
-// kernel computes it to within r = 4e-7 max|coordinate|) to q on a light (distance >= b) meets the plane at parameter
-// t = a dist / (a - b): negative for a > 0, and at most (viol + r) D / b for a < 0, D = the scene's diagonal >= dist.  W is declared
-// a non-occluder only if that bound is below HALF of tmin, so the unmasked test could not have accepted it either — the shadow
-// walk skips such primitives and returns the same answer, bit for bit (tests/test_gpu_render.py, ZDR_NO_SHADOW_MASK=1).  The walls,
-// floor and ceiling of a room lit from inside are the typical case: 3 of the Cornell box's 9 pairs.
-static void never_occluders(const std::vector<h3> &pos, uint32_t ntris, const std::vector<uint8_t> &is_light_tri, std::vector<uint8_t> &never) {
-    never.assign(ntris, 0);
-    bool any_light = false;
-    for (uint32_t t = 0; t < ntris; t++) any_light = any_light || is_light_tri[t];
-    if (!any_light || ntris > 128) return;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, cmax = 0.0;
-    for (size_t i = 0; i < 3 * (size_t)ntris; i++) {
-        const double c[3] = {pos[i].x, pos[i].y, pos[i].z};
-        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], c[k]); hi[k] = std::max(hi[k], c[k]); cmax = std::max(cmax, fabs(c[k])); }
-    }
-    const double D = sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
-    if (!(D > 0.0) || !(D < 1e30)) return;
-    for (uint32_t w = 0; w < ntris; w++) {
-        const h3 *p = &pos[3 * (size_t)w];
-        double e1[3] = {(double)p[1].x - p[0].x, (double)p[1].y - p[0].y, (double)p[1].z - p[0].z}, e2[3] = {(double)p[2].x - p[0].x, (double)p[2].y - p[0].y, (double)p[2].z - p[0].z};
-        double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-        const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-        if (!(nn > 0.0)) continue;                                 // degenerate: never hit, but left in (it costs nothing to be careful)
-        for (int k = 0; k < 3; k++) n[k] /= nn;
-        double dmin = 1e300, dmax = -1e300, lmin = 1e300, lmax = -1e300;
-        for (uint32_t t = 0; t < ntris; t++)
-            for (int k = 0; k < 3; k++) {
-                const h3 &v = pos[3 * (size_t)t + k];
-                const double d = n[0] * ((double)v.x - p[0].x) + n[1] * ((double)v.y - p[0].y) + n[2] * ((double)v.z - p[0].z);
-                dmin = std::min(dmin, d); dmax = std::max(dmax, d);
-                if (is_light_tri[t]) { lmin = std::min(lmin, d); lmax = std::max(lmax, d); }
-            }
-        const double r = 4e-7 * cmax, tmin = 1e-4;
-        const bool above = lmin > 0.0 && (std::max(0.0, -dmin) + r) * D <= 0.5 * tmin * lmin;     // scene on the + side, lights strictly
-        const bool below = lmax < 0.0 && (std::max(0.0, dmax) + r) * D <= 0.5 * tmin * -lmax;
-        never[w] = (above || below) ? 1 : 0;
-    }
-}
-
-// Slot order of the brute-force walk: the two triangles of quad q in slots 2q and 2q + 1, the single triangles after them.  Within the
-// parallelograms, within the other quads and within the single triangles the primitives that can occlude a shadow segment come first
-// (`never`, may be null): the shadow walk then skips whole PAIRS of the others.
-static uint32_t brute_slot_order(const std::vector<h3> &pos, uint32_t ntris, std::vector<int> &order, std::vector<int> &rot, uint32_t *npar = nullptr,
-                                 const std::vector<uint8_t> *never = nullptr) {
+// Slot order of the brute-force walk: the two triangles of quad q in slots 2q and 2q + 1, the single triangles after them.
+static uint32_t brute_slot_order(const std::vector<h3> &pos, uint32_t ntris, std::vector<int> &order, std::vector<int> &rot, uint32_t *npar = nullptr) {
     std::vector<QuadPair> quads;
     rot.assign(ntris, 0);
     if (!getenv("ZDR_NO_QUADS")) find_quads(pos, ntris, rot, quads);
-    auto nv = [&](int t) { return never && (*never)[t]; };
-    std::stable_sort(quads.begin(), quads.end(), [&](const QuadPair &x, const QuadPair &y) {
-        if (x.par != y.par) return (bool)x.par;
-        return (nv(x.a) && nv(x.b)) < (nv(y.a) && nv(y.b)); });
     std::vector<uint8_t> in_quad(ntris, 0);
     order.resize(ntris);
     uint32_t slot = 0;
     for (const QuadPair &q : quads) { order[slot++] = q.a; order[slot++] = q.b; in_quad[q.a] = in_quad[q.b] = 1; }
-    for (int pass = 0; pass < 2; pass++)
-        for (uint32_t t = 0; t < ntris; t++) if (!in_quad[t] && (int)nv((int)t) == pass) order[slot++] = (int)t;
+    for (uint32_t t = 0; t < ntris; t++) if (!in_quad[t]) order[slot++] = (int)t;
     if (npar) { *npar = 0; for (const QuadPair &q : quads) *npar += q.par ? 1u : 0u; }
     return (uint32_t)quads.size();
 }
@@ -377,7 +326,7 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
                     }
                 } else {
                     for (int ax = 0; ax < 3; ax++) { lo[ax][k] = 3e38f; hi[ax][k] = 3e38f; }
-                    child[k] = 0; cnt[k] = -1;     // unused slot: an inverted box (below) that no finite ray enters; count 7 ends a walk that gets there anyway
+                    child[k] = 0; cnt[k] = -1;     // unused slot: the traversal skips cnt < 0
                 }
             }
             worst_stack = std::max(worst_stack, it.stack + nk - 1);
@@ -400,9 +349,6 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
                         return fail(ZDR_E_INVALID, "internal error: BVH box quantisation is not conservative");
                     qlo[ax] |= (uint32_t)a << (8 * k); qhi[ax] |= (uint32_t)b << (8 * k);
                 }
-                // unused child slots: low plane 255, high plane 0 — whatever the sign of the direction the ray would have to enter
-                // after it has left (q_near A + B > q_far A + B for every finite A != 0), so the walk needs no test for them
-                for (int k = nk; k < 4; k++) qlo[ax] |= 255u << (8 * k);
             }
             uint32_t cw[4];
             for (int k = 0; k < 4; k++) cw[k] = (cnt[k] < 0) ? 7u : (((uint32_t)child[k] << 3) | (uint32_t)cnt[k]);
@@ -437,18 +383,6 @@ static int build_accel(const std::vector<h3> &pos, uint32_t ntris, bool use_bvh,
         if (ninner) for (uint32_t t = 0; t < ntris && ok; t++) ok = seen_tri[t] != 0;
         if (!ok) { return fail(ZDR_E_INVALID, "internal error: BVH failed its structural self-check"); }
     }
-    // Child words as the device reads them (accel.h, fetch): the BYTE OFFSET of what the child names inside the one allocation that
-    // holds the nodes (64 bytes each, first) and the plane records (48 bytes per slot, behind them), | the count in the low bits
-    // (offsets are multiples of 16).  The structural check above read the index form.
-    if ((size_t)ninner * 64 + (size_t)ntris * 48 >= (1ull << 32)) return fail(ZDR_E_UNSUPPORTED, "BVH nodes and triangle records exceed 4 GiB");
-    for (int i = 0; i < ninner; i++) {
-        uint32_t cw[4]; memcpy(cw, &nodes[4 * (size_t)i + 3], 16);
-        for (int k = 0; k < 4; k++) {
-            const uint32_t idx = cw[k] >> 3, ct = cw[k] & 7u;
-            cw[k] = (ct == 7u) ? 7u : ((ct == 0u ? idx * 64u : (uint32_t)ninner * 64u + idx * 48u) | ct);
-        }
-        memcpy(&nodes[4 * (size_t)i + 3], cw, 16);
-    }
     bvh_nodes = (uint32_t)ninner; bvh_depth = (uint32_t)bb.max_depth;
     stack_entries = (uint32_t)((worst_stack + 5 + 3) & ~3);   // deepest pending set + the four unconditionally stored slots
     return ZDR_OK;
@@ -464,8 +398,6 @@ struct zdr_scene {
     std::vector<float> emission;
     float4 *d_isect = nullptr, *d_pairs = nullptr, *d_shade = nullptr, *d_nodes = nullptr;
     bool isect_in_nodes = false;            // BVH: d_isect points into the d_nodes allocation (freed once)
-    std::vector<int> slot_tri;              // brute force: slot -> input triangle
-    unsigned long long shadow_pairs = ~0ull;   // brute force: the pairs of the pair walk a shadow segment can meet (never_occluders; rebuilt when the lights change)
     uint32_t nquads = 0, nquads2 = 0, npar = 0;   // brute force: primitives of the pair walk, how many of them are merged quads (find_quads), how many of those parallelograms
     float4 *d_ppairs = nullptr;
     float *d_emission = nullptr;
@@ -525,26 +457,7 @@ static void light_list(const std::vector<float> &em, uint32_t ninst, std::vector
 // emission through four dependent lookups (light.py:33-48); on the GPU that is four memory round trips and eleven
 // per-lane loads per path vertex.  Flattened here to {first entry, T} per light and one 80-byte entry per light
 // triangle {p0} {p1} {p2} {ng, area} {emission, 0}, the same floats the shade records hold.
-// the pairs of the brute-force walk that hold at least one primitive a shadow segment can meet, for the current lights
-static unsigned long long shadow_pair_mask(const zdr_scene *s, const std::vector<int32_t> &lights, int count) {
-    if (s->accel_is_bvh || s->slot_tri.empty() || s->ntris > 128 || getenv("ZDR_NO_SHADOW_MASK")) return ~0ull;
-    std::vector<h3> pos(3 * (size_t)s->ntris);
-    for (uint32_t t = 0; t < s->ntris; t++) for (int k = 0; k < 3; k++) { const float4 &g = s->tri_geo[4 * (size_t)t + k]; pos[3 * (size_t)t + k] = H3(g.x, g.y, g.z); }
-    std::vector<uint8_t> is_light(s->ntris, 0), never;
-    for (int l = 0; l < count; l++) for (int t = s->inst_tri_begin[lights[l]]; t < s->inst_tri_begin[lights[l] + 1]; t++) is_light[t] = 1;
-    never_occluders(pos, s->ntris, is_light, never);
-    unsigned long long m = 0ull;
-    for (uint32_t q = 0; q < s->nquads; q++) {                  // primitive q: slots 2q, 2q + 1 (a quad) or slot q + nquads2 (a single triangle)
-        const bool quad = q < s->nquads2;
-        const uint32_t a = quad ? 2 * q : q + s->nquads2;
-        const bool skip = never[s->slot_tri[a]] && (!quad || never[s->slot_tri[a + 1]]);
-        if (!skip) m |= 1ull << (q / 2);
-    }
-    return m;
-}
-
 static int upload_light_table(zdr_scene *s, const std::vector<int32_t> &lights, int count, hipStream_t st) {
-    s->shadow_pairs = shadow_pair_mask(s, lights, count);
     std::vector<float4> tab; std::vector<int32_t> range(2 * (size_t)s->ninst, 0);
     for (int l = 0; l < count; l++) {
         const int inst = lights[l], b = s->inst_tri_begin[inst], T = s->inst_tri_begin[inst + 1] - b;
@@ -635,11 +548,7 @@ extern "C" int zdr_scene_create(const float *verts8, uint32_t nverts, const int3
     if (!use_bvh) {
         std::vector<h3> pos(3 * (size_t)ntris);
         for (uint32_t t = 0; t < ntris; t++) for (int k = 0; k < 3; k++) pos[3 * (size_t)t + k] = rec[t].p[k];
-        std::vector<uint8_t> is_light(ntris, 0), never;       // (the lights of the moment only ORDER the primitives; the mask itself follows update_lights)
-        for (uint32_t t = 0; t < ntris; t++) { const float *e = &s->emission[3 * (size_t)rec[t].inst]; is_light[t] = (e[0] > 0.0f || e[1] > 0.0f || e[2] > 0.0f) ? 1 : 0; }
-        never_occluders(pos, ntris, is_light, never);
-        s->nquads2 = brute_slot_order(pos, ntris, order, rot, &s->npar, &never); s->nquads = ntris - s->nquads2;
-        s->slot_tri = order;
+        s->nquads2 = brute_slot_order(pos, ntris, order, rot, &s->npar); s->nquads = ntris - s->nquads2;
     }
 
     std::vector<float4> isect(3 * (size_t)ntris + 3, make_float4(0, 0, 0, 0)), shade(8 * (size_t)ntris);   // + one record: the BVH walk fetches four float4 behind a leaf's first triangle
@@ -763,17 +672,6 @@ extern "C" int zdr_debug_build_accel(const float *tri_xyz, uint32_t ntris, int a
         float4 q[3]; plane_record(c, q);
         memcpy(isect_out + 12 * (size_t)slot, q, sizeof q);
     }
-    return ZDR_OK;
-}
-
-// Host-only: the classification behind the shadow walk's pair mask (never_occluders above), for the CPU test-suite.
-extern "C" int zdr_debug_never_occluders(const float *tri_xyz, uint32_t ntris, const uint8_t *is_light_tri, uint8_t *never_out) {
-    if (!tri_xyz || !ntris || !is_light_tri || !never_out) return fail(ZDR_E_INVALID, "null argument");
-    std::vector<h3> pos(3 * (size_t)ntris);
-    for (size_t i = 0; i < 3 * (size_t)ntris; i++) pos[i] = H3(tri_xyz[3 * i], tri_xyz[3 * i + 1], tri_xyz[3 * i + 2]);
-    std::vector<uint8_t> light(is_light_tri, is_light_tri + ntris), never;
-    never_occluders(pos, ntris, light, never);
-    memcpy(never_out, never.data(), ntris);
     return ZDR_OK;
 }
 
@@ -1065,10 +963,7 @@ static int render_common(zdr_scene *s, const zdr_render_params *p, const float *
     if (stats && !io.counters) return fail(ZDR_E_NOMEM, "counter buffer missing");
     if (p->integrator == ZDR_PATH && (!io.ring || !io.work_counters)) return fail(ZDR_E_NOMEM, "path workspace missing");
     if (stats && p->integrator == ZDR_UVGRAD) return fail(ZDR_E_UNSUPPORTED, "no statistics for render_duvdxy");
-    DScene S = s->ds;
-    // shadow segments end on a light's surface; an environment light sends them to infinity, where nothing can be ruled out
-    S.shadow_pairs = (S.env_count > 0) ? ~0ull : s->shadow_pairs;
-    if (zdr_launch_render(S, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
+    if (zdr_launch_render(s->ds, R, C, io, p->integrator, s->accel_is_bvh, backward, stats, (hipStream_t)stream))
         return fail(ZDR_E_HIP, std::string("kernel launch: ") + hipGetErrorString(hipGetLastError()));
     static const bool check_every_call = getenv("ZDR_CHECK") && atoi(getenv("ZDR_CHECK")) != 0;   // opt-in: costs a synchronise per call
     if (check_every_call && !stats && !capturing) return check_device_error(s, (hipStream_t)stream);   // (a synchronise cannot be captured: zdr_scene_check after the replay instead)
@@ -1137,9 +1032,7 @@ extern "C" int zdr_path_dump(zdr_scene *s, const zdr_render_params *p, const flo
     rc = make_sampler_cfg(s, p->sampler, p->seed, p->spp, C); if (rc) return rc;
     KernelIO io; memset(&io, 0, sizeof io);
     io.material = (const float4 *)material; io.d_image = (const float4 *)d_image;
-    DScene S = s->ds;
-    S.shadow_pairs = (S.env_count > 0) ? ~0ull : s->shadow_pairs;
-    if (zdr_launch_path_dump(S, R, C, io, s->accel_is_bvh, queries, n, maxv, out, (hipStream_t)stream)) return fail(ZDR_E_HIP, "path dump launch failed");
+    if (zdr_launch_path_dump(s->ds, R, C, io, s->accel_is_bvh, queries, n, maxv, out, (hipStream_t)stream)) return fail(ZDR_E_HIP, "path dump launch failed");
     return ZDR_OK;
 }
 

@@ -62,4 +62,5 @@ for name, chans in (("diffuse", slice(0, 3)), ("roughness", slice(3, 4)), ("all"
     sig = np.hypot(ad.std(ddof=1), fd.std(ddof=1)) / np.sqrt(a.seeds) / abs(fd.mean())
     res[name] = {"AD": ad.mean(), "AD_se": ad.std(ddof=1) / np.sqrt(a.seeds), "FD": fd.mean(), "FD_se": fd.std(ddof=1) / np.sqrt(a.seeds), "rel_err": rel, "one_sigma": sig}
     print(f"{name:9s}: AD = {ad.mean():.4f} +- {res[name]['AD_se']:.4f}  FD = {fd.mean():.4f} +- {res[name]['FD_se']:.4f}  rel-err {rel:.2e} (1 sigma {sig:.2e})", flush=True)
-json.dump({"scene": a.scene, "integrator": a.integrator, "res": W, "spp": a.spp, "seeds": a.seeds, "fd_eps": a.eps, "result": res}, open(a.out, "w"), indent=1)
+from zdr_amd import build as hip_build
+json.dump({"csrc_sha256": hip_build.source_hash(), "scene": a.scene, "integrator": a.integrator, "res": W, "spp": a.spp, "seeds": a.seeds, "fd_eps": a.eps, "result": res}, open(a.out, "w"), indent=1)

@@ -107,6 +107,7 @@ rel = abs(ad_m - fd_m) / abs(fd_m)
 sigma = np.hypot(fd_se, ad_se) / abs(fd_m)
 print(f"tail: {a.tail_seeds} seeds x 2^{int(np.log2(a.tail_spp))} spp ({time.time() - t0:.1f} s):  FD = {fd_m:.6f} +- {fd_se:.6f}   AD = {ad_m:.6f} +- {ad_se:.6f}")
 print(f"grad rel-err |AD - FD| / |FD| = {rel:.3e}   (statistical resolution 1 sigma = {sigma:.3e})")
-json.dump({"imgidx": imgidx, "texidx": texidx, "fd_eps": FD_EPS, "table_spp": [2 ** e for e in range(13)], "seeds": SEEDS,
+from zdr_amd import build as hip_build
+json.dump({"csrc_sha256": hip_build.source_hash(), "imgidx": imgidx, "texidx": texidx, "fd_eps": FD_EPS, "table_spp": [2 ** e for e in range(13)], "seeds": SEEDS,
            "FD": rows["FD"], "AD": rows["AD"], "tail": {"spp": a.tail_spp, "seeds": a.tail_seeds, "FD": fd_m, "FD_se": fd_se, "AD": ad_m, "AD_se": ad_se,
            "rel_err": rel, "one_sigma": sigma}}, open(a.out, "w"), indent=1)

@@ -25,7 +25,7 @@ COUNTER_NAMES = ("samples", "closest_rays", "closest_hits", "shadow_rays", "shad
 # every symbol include/zdr.h declares
 EXPORTS = ("zdr_version", "zdr_abi_version", "zdr_last_error", "zdr_scene_create", "zdr_scene_destroy", "zdr_scene_info",
            "zdr_scene_set_emissions", "zdr_scene_set_envmap", "zdr_scene_set_pmj02bn_tables", "zdr_render_forward", "zdr_render_backward",
-           "zdr_render_stats", "zdr_scene_check", "zdr_trace_closest", "zdr_trace_any", "zdr_sampler_dump", "zdr_vertex_sampler_dump", "zdr_path_dump", "zdr_debug_build_accel")
+           "zdr_render_stats", "zdr_scene_check", "zdr_trace_closest", "zdr_trace_any", "zdr_sampler_dump", "zdr_vertex_sampler_dump", "zdr_path_dump", "zdr_debug_build_accel", "zdr_debug_never_occluders")
 
 
 class CameraPOD(C.Structure):
@@ -87,6 +87,7 @@ def lib():
     L.zdr_vertex_sampler_dump.argtypes = [vp, C.c_int32, C.c_uint32, C.c_uint32, ip, C.c_uint32, C.c_int32, C.c_int32, fp, C.POINTER(C.c_int32), vp]
     L.zdr_path_dump.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.c_uint32, C.c_int32, fp, vp]
     L.zdr_debug_build_accel.argtypes = [fp, C.c_uint32, C.c_int, fp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), ip, fp]
+    L.zdr_debug_never_occluders.argtypes = [fp, C.c_uint32, vp, vp]
     for name in EXPORTS:
         getattr(L, name)          # AttributeError here = header and library disagree
     if L.zdr_abi_version() != ABI_VERSION:

@@ -112,7 +112,7 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     float u_pick = sampler_next<SK>(C, smp);
     LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, smp); }, [&]() { return sampler_next2<SK>(C, smp); });   // (the batched draw of sampler.h costs this kernel more in spills — 128 VGPRs — than it saves)
     COUNT(C_SHADOW);
-    bool occluded = A::any(S, lds, it.p, light.wi, 1e-4f, light.dist);
+    bool occluded = A::any_shadow(S, lds, it.p, light.wi, 1e-4f, light.dist);
     Onb onb = make_onb(it.ns);
     f3 wo = to_local(onb, -d);
     f3 wil = to_local(onb, light.wi);
@@ -387,7 +387,7 @@ ZD bool path_shade(const DScene &S, const RenderCfg &R, const SamplerCfg &C, con
     } else {
         const ShadeCtx x = shade_ctx<SK, BWD, STATS, ENV>(S, R, C, io, ps, it, pv, cnt);
         COUNT(C_SHADOW);
-        const bool occluded = A::any(S, lds, it.p, x.light.wi, 1e-4f, x.light.dist);
+        const bool occluded = A::any_shadow(S, lds, it.p, x.light.wi, 1e-4f, x.light.dist);
         if (!occluded && x.wil.z >= 1e-4f) nee_apply<BWD>(ps, pv, nee_terms<BWD>(x, ps.beta));
         COUNT(C_SHADOW_TRACED);
         return sample_bsdf<SK, BWD>(R, C, x, ps, it, pv);   // the caller traces the continuation ray (path_continue), after it has put pv away

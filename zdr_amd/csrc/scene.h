@@ -47,6 +47,7 @@ struct DScene {
     int32_t light0_T;               // triangle count of light 0 (the whole table when light_count == 1)
     int32_t ntris, ninst, light_count, nnodes;
     int32_t nquads, nquads2;        // brute-force accel: primitives of the pair walk (quads first, then single triangles) and the number of quads
+    unsigned long long shadow_pairs;   // brute-force accel: bit k set = pair k holds a primitive that a shadow segment (surface point -> light point) can meet; the others support the scene from outside (zdr_api.cpp, never_occluders).  Set per launch.
     const float4 *ppairs; int32_t nppairs;   // the first nppairs pairs hold two parallelograms each: plane + u, v of the first triangle, 6 float4 per pair
     // environment light (envmap.py; heap slots 23330-23332): lat-long RGBA texture + importance tables
     const float4 *env_tex; const float *alias_prob; const int32_t *alias_idx; const float *env_pdf;

@@ -4,7 +4,10 @@ imageio, /root/reference/envmap.py:117-121, which this environment does not ship
 Scope: single-part scan-line files, channels of type HALF / FLOAT / UINT with sampling 1, compression NONE, RLE, ZIPS, ZIP
 (what Blender and OpenEXR's own tools write by default or on request) or PIZ (OpenEXR's historical default, common in HDRI
 libraries; read only — wavelet + Huffman decoding below).  PXR24, B44 and DWA files are refused with a message naming the
-compression.  Layout per the OpenEXR file-layout document: magic 0x01312f76,
+compression.  PIZ CAVEAT: no file written by OpenEXR itself exists in this offline image, so the PIZ decoder is checked only
+against the encoder in tests/test_exr.py, written from the same reading of ImfPizCompressor / ImfHuf / ImfWav — a shared misreading
+of the format would pass.  Its Huffman stage is a Python loop per 16-bit word (about 1.3 M words/s: a 4096 x 2048 half-float map
+takes ~20 s, during which add_envmap looks hung).  Out of the hot path's scope; frozen as it is.  Layout per the OpenEXR file-layout document: magic 0x01312f76,
 version word, attribute list, chunk-offset table, chunks {y, size, data}; inside a chunk the scan lines follow one
 another, each holding its channels in alphabetical order; ZIP data is deflate over a byte-delta predictor applied to the
 even/odd byte split of the chunk.

@@ -154,6 +154,7 @@ struct ScatterQueue {                // pointers into this wave's LDS block
     int copy_base;                   // first cell of this wave's copy of the staging array
     int ncells;                      // (tex_h + 1) x (tex_w + 1)
     float *lds_cells;                // != nullptr: the whole cell array lives here (ncells <= ZDR_LDS_CELLS)
+    bool small;                      // all copies of the cell array together hold fewer than 2^30 floats (wave-uniform)
 #ifdef ZDR_MEASURE_STATS
     unsigned long long st_flushes, st_entries, st_dups;   // measurement build: flushes, entries flushed, entries whose cell an earlier entry of the same flush holds
 #endif
@@ -171,6 +172,7 @@ ZD ScatterQueue scatter_queue_init(float *lds, int tex_h, int tex_w, int cell_co
 #endif
     q.ncells = (tex_h + 1) * (tex_w + 1);
     q.copy_base = (int)(blockIdx.x % (unsigned)cell_copies) * q.ncells;
+    q.small = (unsigned long long)q.ncells * (unsigned long long)cell_copies * 16ull < (1ull << 30);
     q.lds_cells = (q.ncells <= ZDR_LDS_CELLS) ? lds : nullptr;
     if (q.lds_cells) {
         for (int i = threadIdx.x & 63; i < 16 * q.ncells; i += 64) lds[i] = 0.0f;
@@ -212,17 +214,24 @@ ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells, int tex_h, int
         q.st_flushes++; q.st_entries += (unsigned long long)q.count; q.st_dups += (unsigned long long)__popcll(__ballot(dup));
     }
 #endif
+    // corner m = j >> 2 of lane j: bit 1 -> x + 1, bit 0 -> y + 1; its weight is (ox or 1 - ox) (oy or 1 - oy) = fma(ox, ax, bx) fma(oy, ay, by)
+    // with per-lane constants (1 - o == fma(o, -1, 1) exactly): one FMA per factor instead of a subtract and a select in every iteration
+    const float ax = (j & 8) ? 1.0f : -1.0f, bx = (j & 8) ? 0.0f : 1.0f, ay = (j & 4) ? 1.0f : -1.0f, by = (j & 4) ? 0.0f : 1.0f;
     for (int base = 0; base < q.count; base += 4) {
         int e = base + sub;
         if (e < q.count) {
             int cell = q.cell[e];
             float gc = q.g[4 * e + (j & 3)];
             float ox = q.ox[e], oy = q.oy[e];
-            float wx = (j & 8) ? ox : 1.0f - ox;        // corner m = j >> 2: bit 1 -> x + 1, bit 0 -> y + 1
-            float wy = (j & 4) ? oy : 1.0f - oy;
+            float wx = fmaf(ox, ax, bx);
+            float wy = fmaf(oy, ay, by);
             const float add = (wx * wy) * gc;                                  // k_m * dmat.c, interaction.py:82-89
             if (ablate == 6) asm volatile("" ::"v"(add), "v"(cell));          // ablation 6: the whole queue and flush, but no atomic is issued
-            else unsafeAtomicAdd(cells + 16 * (size_t)cell + j, add);
+            else if (q.small) {                                                // the whole cell array within 4 GiB (textures up to 8190^2): scalar base + 32-bit offset,
+                const uint32_t idx = 16u * (uint32_t)cell + (uint32_t)j;       // no 64-bit shift and add per lane and request
+                __builtin_assume(idx < (1u << 30));
+                unsafeAtomicAdd(cells + idx, add);
+            } else unsafeAtomicAdd(cells + 16 * (size_t)cell + j, add);
         }
     }
     __builtin_amdgcn_wave_barrier();

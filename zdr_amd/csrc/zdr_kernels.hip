@@ -406,8 +406,8 @@ __global__ __launch_bounds__(WAVE, A::kMinWavesBwd) void k_path_bwd(ZDR_PATH_KER
         if (took >= 0) {
             {   // the pixel's cotangent / spp, straight from the image (load_le_grad; a popped path is inside the shard)
                 const float4 gi = io.d_image[ps.smp.px + ps.smp.py * (uint32_t)R.width];
-                const float fs = (float)C.spp;
-                le_grad = mk3(__fdiv_rn(gi.x, fs), __fdiv_rn(gi.y, fs), __fdiv_rn(gi.z, fs));
+                if (C.spp_pow2) le_grad = mk3(gi.x * C.inv_spp, gi.y * C.inv_spp, gi.z * C.inv_spp);   // x / 2^k == x * 2^-k exactly: three IEEE divisions (~30 VALU per trip) less
+                else { const float fs = (float)C.spp; le_grad = mk3(__fdiv_rn(gi.x, fs), __fdiv_rn(gi.y, fs), __fdiv_rn(gi.z, fs)); }
                 if (any_nan(le_grad)) le_grad = mk3(0.0f);
             }
             nrec = 0;

@@ -1,16 +1,22 @@
-# Collects what profiles/ and the docs quote for one round: bash tools/final_evidence.sh <tag>   (≈10 min of GPU time)
+# Collects what profiles/ and the docs quote for one round, from THIS tree, in two gpurun calls (a call is limited to 20 minutes):
+#   bash tools/final_evidence.sh <tag> fd        AD against finite differences (≈14 min): copy gpurun_out/<tag>_fd_*.json into profiles/ BEFORE stage 2,
+#                                                so that the bench line of stage 2 quotes them (they carry the hash of the sources they were measured on)
+#   bash tools/final_evidence.sh <tag> profiles  counter passes c3 + c5, one kernel trace per configuration, the bench line, rehearsals (≈16 min)
 cd $GRAFT_REPO_ROOT
-tag=${1:-rX}; out=gpurun_out/${tag}_final; mkdir -p $out
-bash tools/refresh_profiles.sh $tag > $out/refresh.log 2>&1                       # c3: PMC passes, rocprof kernel stats, bench line
-cp gpurun_out/${tag}_pmc.txt gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_kernel_stats.csv gpurun_out/${tag}_bench.json $out/ 2>/dev/null
-bash tools/pmc_big.sh $tag --spp 16 --iters 1 > $out/pmc_c5.txt 2>&1               # c5: lane utilisation, waits
-timeout -k 10 400 python bench.py --config c5 --steps 3 --warmup 1 > $out/bench_c5.json 2> $out/bench_c5.err
-# c5's kernel durations as rocprofv3 sees them (the program directly after `--`): 0.08 of the roofline must be recomputable from a kept csv
-(cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_c5 -- python bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > $out/stats_c5.log 2>&1)
-find gpurun_out/${tag}_stats_c5 -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_c5.csv \;
-timeout -k 10 300 python tools/configs.py > $out/configs.txt 2>&1; cp gpurun_out/configs.json $out/configs.json
-bash tools/rehearse_dist.sh > $out/two_rank_gloo_rehearsal.txt 2>&1
-timeout -k 10 200 python tools/trace_bench.py > $out/trace_bench_1m.txt 2>&1
-timeout -k 10 300 python tools/hotspot_bench.py --out $out/hotspot.json > $out/hotspot.txt 2>&1
-timeout -k 10 600 python tests/measure/full_size_parity.py > $out/full_size_parity.txt 2>&1; cp gpurun_out/full_size_parity.json $out/ 2>/dev/null
-ls $out
+tag=${1:-rX}; stage=${2:-profiles}; mkdir -p gpurun_out
+if [ "$stage" = fd ]; then
+  # the reference's fd_validate.py procedure (one pixel x one texel), diffuse and roughness, and the whole-image directional derivative
+  timeout -k 10 200 python tools/fd_validate.py --channel diffuse --skip-table --tail-spp 4194304 --tail-seeds 1024 --out gpurun_out/${tag}_fd_validate_diffuse_texel.json > gpurun_out/${tag}_fd_validate_diffuse_texel.txt 2>&1 || echo "fd diffuse: FAILED or timed out"
+  tail -2 gpurun_out/${tag}_fd_validate_diffuse_texel.txt
+  timeout -k 10 180 python tools/fd_directional.py --seeds 256 --out gpurun_out/${tag}_fd_directional.json > gpurun_out/${tag}_fd_directional.txt 2>&1 || echo "fd directional: FAILED or timed out"
+  tail -4 gpurun_out/${tag}_fd_directional.txt
+  timeout -k 10 700 python tools/fd_validate.py --channel roughness --skip-table --tail-spp 4194304 --tail-seeds 7168 --out gpurun_out/${tag}_fd_validate_roughness_texel.json > gpurun_out/${tag}_fd_validate_roughness_texel.txt 2>&1 || echo "fd roughness: FAILED or timed out"
+  tail -2 gpurun_out/${tag}_fd_validate_roughness_texel.txt
+  exit 0
+fi
+bash tools/refresh_profiles.sh $tag > gpurun_out/${tag}_refresh.log 2>&1
+grep "refresh_profiles\]" gpurun_out/${tag}_refresh.log
+tail -c 1500 gpurun_out/${tag}_bench.json
+timeout -k 10 100 python tools/trace_bench.py > gpurun_out/${tag}_trace_bench_1m.txt 2>&1; grep Mrays gpurun_out/${tag}_trace_bench_1m.txt
+ZDR_DIST_BACKEND=gloo ZDR_SHARE_DEVICE=1 timeout -k 10 200 python bench.py --gpus 2 --steps 2 --warmup 1 2> gpurun_out/${tag}_two_rank_gloo.err | grep '^{' > gpurun_out/${tag}_two_rank_gloo_line.json
+ls gpurun_out | grep "^${tag}_"

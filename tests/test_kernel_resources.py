@@ -79,3 +79,11 @@ def test_forward_path_kernel_holds_four_waves_per_simd_without_spills():
     the loop) went with the kernarg reload, and the two VGPRs that carried them with them."""
     for name, r in pick(kernels(), r"k_pathILi0E10BruteAccelLb0ELb0E").items():
         assert r["vgpr_count"] <= 128 and r["private_segment_fixed_size"] == 0, (name, r)
+
+
+def test_backward_path_kernel_spills_nothing_brute_force():
+    """k_path_bwd<cmj, BruteAccel>: its private segment is the overflow records of the pool (16 x 80 bytes + 16 links, rounded: 1,376 bytes)
+    and NOTHING else.  The kernel sits exactly at 128 VGPRs; round 4 measured what four more live registers cost — four spilled dwords in
+    the hot loop, 1,392 bytes, 10.7 -> 11.5 ms (+7 %) — with every other figure of this file unchanged.  A guard, not a tuning knob."""
+    for name, r in pick(kernels(), r"k_path_bwdILi0E10BruteAccelLb0E").items():
+        assert r["private_segment_fixed_size"] <= 1376, (name, r)

@@ -23,7 +23,7 @@ def parse(path):
     rows = {}
     for line in open(path):
         m = re.match(r"void (k_path(?:_bwd)?)<.*?(\{.*\})\s*$", line)
-        if not m: continue
+        if not m or re.match(r"void k_path<\d, \w+, true", line): continue     # (the counting variant of zdr_render_stats is another kernel: STATS = true)
         rows.setdefault("k_path_bwd" if m.group(1) == "k_path_bwd" else "k_path_fwd", {}).update({k: float(v) for k, v in ast.literal_eval(m.group(2)).items()})
     return rows
 def record(k, r):

@@ -270,16 +270,17 @@ struct BvhAccel {
     // A work item is (id, cnt): cnt == 0 -> node id, 1..4 -> leaf slots [id, id + cnt); 7 marks an unused child and is never pushed.
     struct Walker {                  // one ray in flight on this lane
         f3 o, d, inv; float tmin; Hit h;          // h.slot while walking: the hit triangle's record as a 16-byte offset from S.walk_base (slot_of), -1 = none
-        int sp; uint32_t off; int cnt, budget;    // what the ray stands on: byte offset from S.walk_base of a node (cnt == 0) or of a leaf's first plane record (cnt 1..2); 7 = an unused child slot
+        int sp; uint32_t off; int cnt;            // what the ray stands on: byte offset from S.walk_base of a node (cnt == 0) or of a leaf's first plane record (cnt 1..2); 7 = an unused child slot
     };
     ZD static int root_count(const DScene &S) { return (S.nnodes == 0) ? S.ntris : 0; }
-    // Watchdog: a correct walk visits every node and leaf at most once.  The bound makes it impossible for a wave to
-    // spin forever whatever the node data or the ray (NaNs) look like.
+    // Watchdog: a correct walk visits every node and leaf at most once, so a lane's two rays need at most twice that many trips of the
+    // wave's loop — which counts its trips in ONE wave-uniform (scalar) counter: the bound makes it impossible for a wave to spin forever
+    // whatever the node data or the rays (NaNs) look like, at no cost to the vector ALU (a per-lane budget was two VALU in every trip).
     ZD static int walk_budget(const DScene &S) { return (S.debug_bvh_budget > 0) ? S.debug_bvh_budget : 2 * (S.nnodes + S.ntris) + 8; }
     ZD static void start(const DScene &S, Walker &w, f3 o, f3 d, float tmin, float tmax) {
         w.o = o; w.d = d; w.tmin = tmin; w.inv = mk3(rcp(d.x), rcp(d.y), rcp(d.z));
         w.h.slot = -1; w.h.u = 0.0f; w.h.v = 0.0f; w.h.t = tmax;
-        w.sp = 0; w.off = (S.nnodes == 0) ? S.isect_off : 0u; w.cnt = root_count(S); w.budget = walk_budget(S);
+        w.sp = 0; w.off = (S.nnodes == 0) ? S.isect_off : 0u; w.cnt = root_count(S);
     }
     // the slot of the triangle whose plane record starts `units` 16-byte units behind S.walk_base (records are 48 bytes)
     ZD static int slot_of(const DScene &S, int units) { return (int)(__umulhi((uint32_t)units - (S.isect_off >> 4), 0xAAAAAAABu) >> 1); }
@@ -294,7 +295,7 @@ struct BvhAccel {
     // entries on a 1 M triangle tree, 11 KiB of LDS per wave) is a worst case that real rays almost never approach,
     // and LDS is what limits the waves per CU of the BVH kernels.
     struct Fetched { float4 n0, n1, n2, n3, n4, n5; bool dead; };
-    // No slot of a Fetched is zero-filled: n0..n3 are loaded by every lane (a lane whose budget has run out reads the first records of
+    // No slot of a Fetched is zero-filled: n0..n3 are loaded by every lane (a lane that stands on an unused slot reads the first records of
     // the triangle array instead — any valid address — and consume() looks at `dead` before anything else), n4 / n5 are written only
     // for a leaf of more than one triangle, which is exactly when consume() reads them.  Zero-filling the 24 registers cost 23 v_mov in
     // EVERY trip of the walk (a frozen undef is materialised as a zero too): 7 % of its instructions.
@@ -306,7 +307,7 @@ struct BvhAccel {
     // here: such a ray hits nothing.
     ZD static Fetched fetch(const DScene &S, int *stack, Walker &w) {
         Fetched f;
-        f.dead = (--w.budget < 0) | (w.cnt == 7);
+        f.dead = (w.cnt == 7);
         const uint32_t off = f.dead ? S.isect_off : w.off;      // (a dead lane reads the first records of the triangle array: >= 2 records = 6 float4 are always there)
         const float4 *p = (const float4 *)(S.walk_base + off);
         f.n0 = p[0]; f.n1 = p[1]; f.n2 = p[2]; f.n3 = p[3];
@@ -411,10 +412,11 @@ struct BvhAccel {
         // mask.  (Written as `for (;;) { if (step()) continue; ...restart...; continue; }` the compiler splits the loop in two nested
         // ones — an inner one that runs until EVERY lane's current ray has ended, an outer one that restarts them together — and the
         // wave's trip count becomes max(first walks) + max(second walks) instead of max(first + second): found in the ISA in round 3.)
+        int trips_left = ((HAS_A && HAS_B) ? 2 : 1) * walk_budget(S);   // wave-uniform
         while (__ballot(active) != 0ull) {
+            if (--trips_left < 0) { raise_device_error(S, ZDR_DEVERR_BVH_BUDGET); break; }   // the walks were cut short: whatever they return is not a result
             if (active) {
                 if (!step(S, stack, LN, deep, w, first)) {   // this lane's current ray has ended
-                    if (w.budget < 0) raise_device_error(S, ZDR_DEVERR_BVH_BUDGET);   // the walk was cut short: whatever it returns is not a result
                     if (first) {
                         occ = w.h.slot >= 0;
                         first = false;

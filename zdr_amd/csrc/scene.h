@@ -214,17 +214,14 @@ ZD void scatter_flush(ScatterQueue &q, float *__restrict__ cells, int tex_h, int
         q.st_flushes++; q.st_entries += (unsigned long long)q.count; q.st_dups += (unsigned long long)__popcll(__ballot(dup));
     }
 #endif
-    // corner m = j >> 2 of lane j: bit 1 -> x + 1, bit 0 -> y + 1; its weight is (ox or 1 - ox) (oy or 1 - oy) = fma(ox, ax, bx) fma(oy, ay, by)
-    // with per-lane constants (1 - o == fma(o, -1, 1) exactly): one FMA per factor instead of a subtract and a select in every iteration
-    const float ax = (j & 8) ? 1.0f : -1.0f, bx = (j & 8) ? 0.0f : 1.0f, ay = (j & 4) ? 1.0f : -1.0f, by = (j & 4) ? 0.0f : 1.0f;
     for (int base = 0; base < q.count; base += 4) {
         int e = base + sub;
         if (e < q.count) {
             int cell = q.cell[e];
             float gc = q.g[4 * e + (j & 3)];
             float ox = q.ox[e], oy = q.oy[e];
-            float wx = fmaf(ox, ax, bx);
-            float wy = fmaf(oy, ay, by);
+            float wx = (j & 8) ? ox : 1.0f - ox;        // corner m = j >> 2: bit 1 -> x + 1, bit 0 -> y + 1
+            float wy = (j & 4) ? oy : 1.0f - oy;       // (per-lane constants a, b with w = fma(o, a, b) save two VALU per iteration and cost four VGPRs the kernel does not have: four more spills, +0.8 ms — measured, round 4)
             const float add = (wx * wy) * gc;                                  // k_m * dmat.c, interaction.py:82-89
             if (ablate == 6) asm volatile("" ::"v"(add), "v"(cell));          // ablation 6: the whole queue and flush, but no atomic is issued
             else if (q.small) {                                                // the whole cell array within 4 GiB (textures up to 8190^2): scalar base + 32-bit offset,

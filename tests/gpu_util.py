@@ -59,7 +59,7 @@ class Flips:
     number of flipped paths by what the oracle's own IEEE and FMA builds differ by.  (Round 2 allowed a blanket 20 flipped
     paths wherever a test passed its path count; that constant is gone.)"""
 
-    def __init__(self, scene, S, Sf, mat, res, spp, seed, cot=None, what="", traces=None, **params_kw):
+    def __init__(self, scene, S, Sf, mat, res, spp, seed, cot=None, what="", traces=None, uv_tol=None, **params_kw):
         """S / Sf: the oracle scene in its IEEE and FMA builds, in the same state as `scene` (emissions, environment, sampler
         tables).  seed: the seed of the paths to compare — seed for a forward image, seed + 1 for the gradient of
         render_backward(..., seed).  traces: (hip, ref, fma) Trace objects of these very paths, if the caller has them."""
@@ -78,8 +78,8 @@ class Flips:
             hip, ref, fma = traces
         self.hip, self.ref, self.fma = hip, ref, fma
         self.n_paths = q.shape[0]
-        flipped = ~hip.signature_equal(ref)
-        flipped_floor = ~fma.signature_equal(ref)
+        flipped = ~hip.signature_equal(ref, uv_tol)            # uv_tol: path_trace.Trace.signature_equal (the 1 M-triangle scene only)
+        flipped_floor = ~fma.signature_equal(ref, uv_tol)
         self.count, self.floor_count = int(flipped.sum()), int(flipped_floor.sum())
         both = flipped | flipped_floor
         self.pixels = np.zeros((H, W), bool)

@@ -38,12 +38,18 @@ class Trace:
         k = np.arange(self.maxv)[None, :]
         self.live = k < np.minimum(self.nvert, self.maxv)[:, None]     # (n, maxv): vertex k exists
 
-    def signature_equal(self, other):
+    def signature_equal(self, other, uv_tol=None):
         """Paths whose every discrete decision agrees: number of vertices, the triangle hit at each vertex, whether the
-        light sample contributed, whether the path went on, and the kind of Russian-roulette event."""
+        light sample contributed, whether the path went on, and the kind of Russian-roulette event.
+        uv_tol (finely tessellated scenes only): a vertex that lands on ANOTHER triangle of the same instance within uv_tol of the
+        other build's texture coordinates — across a shared edge of a smooth surface, where material and shading normal are
+        continuous — is the same decision, not a branch; its values are then COMPARED instead of set aside."""
         same = self.nvert == other.nvert
         both = self.live & other.live
-        ok = (self.inst == other.inst) & (self.prim == other.prim) & (self.decisions == other.decisions)
+        where = self.prim == other.prim
+        if uv_tol is not None:
+            where = where | (np.abs(self.uv - other.uv).max(axis=2) <= uv_tol)
+        ok = (self.inst == other.inst) & where & (self.decisions == other.decisions)
         return same & np.all(ok | ~both, axis=1)
 
 
@@ -73,10 +79,10 @@ def scatter_gradients(tr, tex_h, tex_w):
     return out
 
 
-def deviation_percentiles(got, ref, pct=(50, 90, 99, 100)):
+def deviation_percentiles(got, ref, pct=(50, 90, 99, 100), uv_tol=None):
     """Per path, over the paths whose signatures agree: the largest deviation of the radiance (relative to the path's own
     radiance) and of the vertex gradients (relative to the path's largest gradient component)."""
-    same = got.signature_equal(ref)
+    same = got.signature_equal(ref, uv_tol)
     finite = same & ~np.isnan(ref.L).any(axis=1) & ~np.isnan(got.L).any(axis=1)
     a, b = got.L[finite].astype(np.float64), ref.L[finite].astype(np.float64)
     lit = np.linalg.norm(b, axis=1) > 0

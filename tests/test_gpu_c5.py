@@ -63,13 +63,20 @@ def test_forward_and_backward_match_the_oracle(material, million):
     q = all_queries(W, H, spp)
     tr = Trace(scene.path_dump(m.detach(), torch.from_numpy(q).cuda(), (W, H), spp, seed + 1, d_image=torch.from_numpy(cot).cuda()).cpu().numpy())
     rt = Trace(S.path_dump(oracle_params(scene, W, H, spp, seed + 1, mat.shape[:2]), mat, q, d_image=cot))
-    st = deviation_percentiles(tr, rt)
-    print(f"[paths] 1M triangles material {material}: {st}")
+    # On this mesh of 6 mm triangles a hit that differs in the fifth digit lands on the NEIGHBOURING triangle: another primitive id, the same
+    # surface point for every purpose (uv, material, interpolated normal are continuous across the shared edge).  Counted as a branch, such
+    # paths were 3.8 % of the glossy render and took a third of its pixels out of the whole-image assertions.  A vertex
+    # within UV_TOL of the oracle's texture coordinates (a fifth of a grid cell, 1 / 183 = 5.5e-3) on the same instance is now the same decision:
+    # the path is COMPARED value by value.  The strict count is printed beside it.
+    UV_TOL = 1e-3
+    strict = deviation_percentiles(tr, rt)
+    st = deviation_percentiles(tr, rt, uv_tol=UV_TOL)
+    print(f"[paths] 1M triangles material {material}: {st} (primitive ids compared strictly: {strict['flipped']} flipped)")
     # flipped paths are bounded by the ruler used everywhere else (gpu_util.Flips.check_count): max(5, 2 x what the oracle's own
     # IEEE and FMA builds differ by) — a hit next to a shared edge of the 6 mm triangles reports the neighbour in either build
     # (measured: 42 against the ruler's 33 of 73,728 on the rough material)
     fma_b = Trace(Sf.path_dump(oracle_params(scene, W, H, spp, seed + 1, mat.shape[:2]), mat, q, d_image=cot))
-    fl = deviation_percentiles(fma_b, rt)
+    fl = deviation_percentiles(fma_b, rt, uv_tol=UV_TOL)
     print(f"[paths] 1M triangles material {material}, oracle fma vs ieee: {fl}")
     assert st["flipped"] <= max(5, 2 * fl["flipped"]), (st, fl)
     if material == "A":
@@ -87,8 +94,8 @@ def test_forward_and_backward_match_the_oracle(material, million):
     # set aside (their pixels / texel footprints), everything else meets the bars — for the glossy material the bars
     # calibrated by the oracle's own FMA build, as everywhere (gpu_util.assert_image_parity).
     pb = oracle_params(scene, W, H, spp, seed + 1, mat.shape[:2])
-    fb = Flips(scene, S, Sf, mat, (W, H), spp, seed + 1, cot=cot, what=f"1M triangles backward {material}", traces=(tr, rt, fma_b))
-    ff = Flips(scene, S, Sf, mat, (W, H), spp, seed, what=f"1M triangles forward {material}")
+    fb = Flips(scene, S, Sf, mat, (W, H), spp, seed + 1, cot=cot, what=f"1M triangles backward {material}", traces=(tr, rt, fma_b), uv_tol=UV_TOL)
+    ff = Flips(scene, S, Sf, mat, (W, H), spp, seed, what=f"1M triangles forward {material}", uv_tol=UV_TOL)
     pf = oracle_params(scene, W, H, spp, seed, mat.shape[:2])
     glossy = material == "B"
     assert_image_parity(img.detach().cpu().numpy()[..., :3], ref[..., :3], f"1M triangles forward {material}", flips=ff,

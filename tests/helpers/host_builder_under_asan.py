@@ -28,6 +28,15 @@ for accel in (_native.ACCEL_BRUTE, _native.ACCEL_BVH):
     order = np.zeros(6, np.int32); isect = np.zeros((6, 12), np.float32); nodes = np.zeros((16, 16), np.float32)
     rc = L.zdr_debug_build_accel(bad.ctypes.data, 6, accel, nodes.ctypes.data, 16, C.byref(nq), C.byref(se), order.ctypes.data, isect.ctypes.data)
     print("degenerate", accel, rc, sorted(order.tolist()))
+# the shadow walk's classification (zdr_debug_never_occluders): real scenes, every / no triangle a light, degenerate and NaN triangles
+for arrays in (A, multi_light_arrays()):
+    tri = E.world_triangles(arrays)
+    lights = np.zeros(tri.shape[0], bool)
+    for i in range(1, arrays.ninst): lights[arrays.inst_tri_begin[i]:arrays.inst_tri_begin[i + 1]] = True
+    for flags in (lights, np.ones_like(lights), np.zeros_like(lights)):
+        print("never", tri.shape[0], int(flags.sum()), int(Q.never_occluders(tri, flags).sum()))
+print("never degenerate", Q.never_occluders(bad.reshape(6, 3, 3), np.array([0, 0, 0, 1, 0, 0], bool)).tolist())
+print("never null", L.zdr_debug_never_occluders(None, 0, None, None))
 # argument checks that return before any HIP call
 h = C.c_void_p()
 print("create(null)", L.zdr_scene_create(None, 0, None, 0, None, None, None, 0, 0, 0, C.byref(h)), L.zdr_last_error().decode()[:40])

@@ -66,6 +66,9 @@ def test_pmj02bn_draws_bit_exact_with_synthetic_tables():
             for k in range(q.shape[0]):
                 exp = oracle.sampler_dump(oracle.SAMPLER_PMJ02BN, int(q[k, 0]), int(q[k, 1]), seed, spp, int(q[k, 2]), nvert=4)
                 assert (got[k, :exp.shape[0]].view(np.uint32) == exp.view(np.uint32)).all(), (spp, seed, q[k])
+            # the path kernels' route for this sampler is the calls one by one: same numbers, and the library says so
+            as_kernels, batched = scene.vertex_sampler_dump(torch.from_numpy(q).cuda(), spp, seed=seed, nvert=4)
+            assert not batched and (as_kernels.cpu().numpy().view(np.uint32) == got.view(np.uint32)).all()
 
 
 def test_pmj02bn_without_tables_fails_loudly_at_the_c_abi():

@@ -44,9 +44,12 @@ def test_cmj_draws_of_the_path_kernels_bit_exact(spp):
             exp = oracle.sampler_dump(oracle.SAMPLER_CMJ, int(q[k, 0]), int(q[k, 1]), seed, spp, int(q[k, 2]), nvert=nvert)
             assert exp.shape[0] == 2 + 7 * nvert + (nvert - 2)      # next2f, seven per vertex, a roulette draw from vertex 2 on
             assert (got[k, :exp.shape[0]].view(np.uint32) == exp.view(np.uint32)).all(), (spp, seed, q[k])
-        # and the two routes of the library agree with each other on every draw
+        # and the routes of the library agree with each other on every draw: one by one, as the path kernels group them, as the direct kernels do
+        # (direct_sample: the pixel's draw packed, the vertex's numbers one by one)
         plain = scene.sampler_dump(torch.from_numpy(q).cuda(), spp, seed=seed, nvert=nvert).cpu().numpy()
         assert (plain.view(np.uint32) == got.view(np.uint32)).all(), (spp, seed)
+        as_direct, b2 = scene.vertex_sampler_dump(torch.from_numpy(q).cuda(), spp, seed=seed, nvert=nvert, integrator="direct")
+        assert b2 == batched and (as_direct.cpu().numpy().view(np.uint32) == got.view(np.uint32)).all(), (spp, seed)
 
 
 def test_pmj02bn_draws_bit_exact_with_synthetic_tables():

@@ -84,7 +84,7 @@ def lib():
     L.zdr_trace_closest.argtypes = [vp, fp, C.c_uint32, ip, fp, vp]
     L.zdr_trace_any.argtypes = [vp, fp, C.c_uint32, ip, vp]
     L.zdr_sampler_dump.argtypes = [vp, C.c_int32, C.c_uint32, C.c_uint32, ip, C.c_uint32, C.c_int32, C.c_int32, fp, vp]
-    L.zdr_vertex_sampler_dump.argtypes = [vp, C.c_int32, C.c_uint32, C.c_uint32, ip, C.c_uint32, C.c_int32, C.c_int32, fp, C.POINTER(C.c_int32), vp]
+    L.zdr_vertex_sampler_dump.argtypes = [vp, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, ip, C.c_uint32, C.c_int32, C.c_int32, fp, C.POINTER(C.c_int32), vp]
     L.zdr_path_dump.argtypes = [vp, C.POINTER(RenderParams), fp, fp, ip, C.c_uint32, C.c_int32, fp, vp]
     L.zdr_debug_build_accel.argtypes = [fp, C.c_uint32, C.c_int, fp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), ip, fp]
     L.zdr_debug_never_occluders.argtypes = [fp, C.c_uint32, vp, vp]

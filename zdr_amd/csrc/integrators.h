@@ -16,7 +16,7 @@ ZD float tent_warp1(float u) {                                   // camera.py:20
 // integrator.py:19-24 + camera.py:5-17
 template <int SK>
 ZD void pixel_ray(const RenderCfg &R, const SamplerCfg &C, Sampler &smp, int x, int y, f3 &o, f3 &d) {
-    f2 off = sampler_next2<SK>(C, smp);
+    f2 off = sampler_pixel_offset<SK>(C, smp);
     if (R.use_tent) { off.x = tent_warp1(off.x) + 0.5f; off.y = tent_warp1(off.y) + 0.5f; }
     float px = R.two_over_w * ((float)x + off.x) - 1.0f;
     float py = R.two_over_h * ((float)y + off.y) - 1.0f;
@@ -109,8 +109,11 @@ ZD f3 direct_sample(const DScene &S, const RenderCfg &R, const SamplerCfg &C, co
     COUNT(C_SHADED);
     float4 mat_grad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     f3 radiance = mk3(0.0f);
+    // (Only the pixel's draw is packed in this kernel, pixel_ray.  Drawing the vertex's numbers in packed passes — all seven at once as the path kernels do,
+    // or group by group: (light, triangle) in one pass, either 2-D draw as an index pass + one packed pass, six passes instead of nine — costs it more in
+    // spills at 128 VGPRs than the passes save: 1.12 -> 1.18 ms in round 3, 0.873 / 1.05 -> 0.883 / 1.10 ms in round 4.)
     float u_pick = sampler_next<SK>(C, smp);
-    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, smp); }, [&]() { return sampler_next2<SK>(C, smp); });   // (the batched draw of sampler.h costs this kernel more in spills — 128 VGPRs — than it saves)
+    LightSample light = sample_light<ENV>(S, it.p, u_pick, [&]() { return sampler_next<SK>(C, smp); }, [&]() { return sampler_next2<SK>(C, smp); });
     COUNT(C_SHADOW);
     bool occluded = A::any_shadow(S, lds, it.p, light.wi, 1e-4f, light.dist);
     Onb onb = make_onb(it.ns);

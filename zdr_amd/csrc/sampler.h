@@ -220,6 +220,31 @@ ZD VertexSamples cmj_vertex_samples(const SamplerCfg &c, Sampler &s) {
     s.dimension += 7;
     return v;
 }
+// The pixel's 2-D draw (integrator.py:19, corrmj.py:105-117) with the two stratum permutations in the halves of one register: the index permutation in its
+// scalar form, then sx and sy in one packed pass — two passes instead of three.  Same values bit for bit; valid under cmj_can_batch.
+ZD f2 cmj_next2_packed(const SamplerCfg &c, Sampler &s) {
+    const uint32_t M = 0x70ffffffu;
+    const uint32_t ps = s.permutation_seed + s.dimension;
+    const uint32_t index = permutation_element(s.sample_index, c.spp, c.w, (ps * 0x51633e2du) & M);
+    const uint32_t x = index & (c.res_x - 1u), y = index >> c.res_x_shift;
+    const uint32_t WR = c.resw_x | (c.resw_y << 16);
+    const bool small_r = (c.resw_x | c.resw_y) < 2048u;
+    const uint32_t sxy = permutation_element2(x | (y << 16), WR, (ps * 0x68bc21ebu) & M, (ps * 0x02e5be93u) & M, small_r);
+    const float dx = next_lcg(s), dy = next_lcg(s);
+    const float ax = (float)(sxy >> 16) + dx, ay = (float)(sxy & 0xffffu) + dy;          // (sy + dx, sx + dy)
+    f2 u;
+    u.x = clampf(((float)x + ax * c.inv_res_y) * c.inv_res_x, 0.0f, ZDR_ONE_MINUS_EPS);
+    u.y = clampf(((float)y + ay * c.inv_res_x) * c.inv_res_y, 0.0f, ZDR_ONE_MINUS_EPS);
+    s.dimension += 2;
+    return u;
+}
+// the first draw of every camera sample, by the route the kernels take (pixel_ray, and zdr_vertex_sampler_dump beside it)
+template <int KIND>
+ZD f2 sampler_pixel_offset(const SamplerCfg &c, Sampler &s) {
+    if (KIND == 0 && cmj_can_batch(c)) return cmj_next2_packed(c, s);       // wave-uniform
+    return sampler_next2<KIND>(c, s);
+}
+
 // sampler_next<cmj> with the permutation already done (cmj_vertex_samples' i_rr): corrmj.py:95-102
 ZD float cmj_next_with_index(const SamplerCfg &c, Sampler &s, uint32_t index) {
     const float delta = next_lcg(s);

@@ -1153,14 +1153,15 @@ extern "C" int zdr_sampler_dump(zdr_scene *s, int32_t sampler, uint32_t seed, ui
     return ZDR_OK;
 }
 
-extern "C" int zdr_vertex_sampler_dump(zdr_scene *s, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries, uint32_t n,
+extern "C" int zdr_vertex_sampler_dump(zdr_scene *s, int32_t integrator, int32_t sampler, uint32_t seed, uint32_t spp, const int32_t *queries, uint32_t n,
                                        int32_t nvert, int32_t rr_depth, float *out, int32_t *batched, void *stream) {
     if (!s || !queries || !out || nvert < 0) return fail(ZDR_E_INVALID, "bad argument");
+    if (integrator != ZDR_PATH && integrator != ZDR_DIRECT) return fail(ZDR_E_INVALID, "the path and the direct integrator have draw routes of their own");
     HIPCHK(hipSetDevice(s->device));
     SamplerCfg C;
     int rc = make_sampler_cfg(s, sampler, seed, spp, C); if (rc) return rc;
     int b = 0;
-    if (zdr_launch_sampler_dump(C, queries, n, nvert, rr_depth, out, 1, &b, (hipStream_t)stream)) return fail(ZDR_E_HIP, "sampler dump launch failed");
+    if (zdr_launch_sampler_dump(C, queries, n, nvert, rr_depth, out, integrator == ZDR_DIRECT ? 2 : 1, &b, (hipStream_t)stream)) return fail(ZDR_E_HIP, "sampler dump launch failed");
     if (batched) *batched = b;
     return ZDR_OK;
 }

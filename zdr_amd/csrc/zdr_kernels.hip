@@ -979,7 +979,7 @@ __global__ void k_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n, int n
 // vertex all seven numbers at once through cmj_vertex_samples (two Kensler permutations per register) and the roulette draw through
 // cmj_next_with_index — whenever cmj_can_batch(C), which is every BASELINE configuration — else the calls one by one.
 template <int SK>
-__global__ void k_vertex_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n, int nvert, int rr_depth, float *out) {
+__global__ void k_vertex_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n, int nvert, int rr_depth, int direct, float *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t px = (uint32_t)q[3 * i], py = (uint32_t)q[3 * i + 1], idx = (uint32_t)q[3 * i + 2];
@@ -988,10 +988,16 @@ __global__ void k_vertex_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n
     const int stride = 2 + 8 * nvert;
     float *o = out + (size_t)i * stride;
     int k = 0;
-    f2 u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+    f2 u = sampler_pixel_offset<SK>(C, s); o[k++] = u.x; o[k++] = u.y;       // pixel_ray's draw
     const bool pre = (SK == 0) && cmj_can_batch(C);             // shade_ctx's x.pre (without an environment light)
     for (int v = 0; v < nvert; v++) {
-        if (pre) {
+        if (pre && direct) {                                    // direct_sample (integrators.h): after the packed pixel draw, the calls one by one
+            o[k++] = sampler_next<SK>(C, s); o[k++] = sampler_next<SK>(C, s);
+            u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+            o[k++] = sampler_next<SK>(C, s);
+            u = sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;
+            if (v >= rr_depth) o[k++] = sampler_next<SK>(C, s);
+        } else if (pre) {
             const VertexSamples vs = cmj_vertex_samples(C, s);
             o[k++] = vs.u_pick; o[k++] = vs.u_prim; o[k++] = vs.u_pt.x; o[k++] = vs.u_pt.y; o[k++] = vs.u_lobe; o[k++] = vs.u_dir.x; o[k++] = vs.u_dir.y;
             if (v >= rr_depth) o[k++] = cmj_next_with_index(C, s, vs.i_rr);
@@ -1006,13 +1012,15 @@ __global__ void k_vertex_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n
     for (; k < stride; k++) o[k] = 0.0f;
 }
 
+// as_kernels: 0 = the calls one by one, 1 = as the path kernels draw, 2 = as the direct kernels draw
 int zdr_launch_sampler_dump(const SamplerCfg &C, const int32_t *queries, uint32_t n, int32_t nvert, int32_t rr_depth, float *out, int as_path_kernels, int *batched, hipStream_t st) {
+    const int direct = as_path_kernels == 2;
     if (batched) *batched = (as_path_kernels && C.kind == ZDR_SAMPLER_CMJ && cmj_can_batch(C)) ? 1 : 0;
     if (n == 0) return 0;
     dim3 grid((n + 63) / 64);
     if (as_path_kernels) {
-        if (C.kind == ZDR_SAMPLER_CMJ) hipLaunchKernelGGL(k_vertex_sampler_dump<0>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
-        else hipLaunchKernelGGL(k_vertex_sampler_dump<1>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
+        if (C.kind == ZDR_SAMPLER_CMJ) hipLaunchKernelGGL(k_vertex_sampler_dump<0>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, direct, out);
+        else hipLaunchKernelGGL(k_vertex_sampler_dump<1>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, direct, out);
     } else if (C.kind == ZDR_SAMPLER_CMJ) hipLaunchKernelGGL(k_sampler_dump<0>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
     else hipLaunchKernelGGL(k_sampler_dump<1>, grid, dim3(64), 0, st, C, queries, n, nvert, rr_depth, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;

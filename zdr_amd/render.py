@@ -253,13 +253,13 @@ class Scene:
         N.check(N.lib().zdr_sampler_dump(self._handle, N.SAMPLERS[self.sampler], int(seed) & 0xFFFFFFFF, int(spp), q.data_ptr(), q.shape[0], nvert, rr_depth, out.data_ptr(), self._stream()))
         return out
 
-    def vertex_sampler_dump(self, queries, spp, seed=0, nvert=3, rr_depth=RR_DEPTH):
-        """As sampler_dump, but drawn the way the path kernels draw (include/zdr.h, zdr_vertex_sampler_dump).
+    def vertex_sampler_dump(self, queries, spp, seed=0, nvert=3, rr_depth=RR_DEPTH, integrator="path"):
+        """As sampler_dump, but drawn the way the path (or the direct) kernels draw (include/zdr.h, zdr_vertex_sampler_dump).
         Returns (draws, batched): batched is True when the packed two-permutations-per-register route ran."""
         q = queries.reshape(-1, 3).to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty((q.shape[0], 2 + 8 * nvert), dtype=torch.float32, device=self.device)
         b = C.c_int32(-1)
-        N.check(N.lib().zdr_vertex_sampler_dump(self._handle, N.SAMPLERS[self.sampler], int(seed) & 0xFFFFFFFF, int(spp), q.data_ptr(), q.shape[0], nvert, rr_depth, out.data_ptr(), C.byref(b), self._stream()))
+        N.check(N.lib().zdr_vertex_sampler_dump(self._handle, N.INTEGRATORS[integrator], N.SAMPLERS[self.sampler], int(seed) & 0xFFFFFFFF, int(spp), q.data_ptr(), q.shape[0], nvert, rr_depth, out.data_ptr(), C.byref(b), self._stream()))
         return out, bool(b.value)
 
     def path_dump(self, material, queries, res, spp, seed, *, d_image=None, maxv=16):

@@ -182,9 +182,10 @@ int zdr_sampler_dump(zdr_scene *scene, int32_t sampler, uint32_t seed, uint32_t 
  * vertex's seven numbers at once with two Kensler permutations per register (csrc/sampler.h, cmj_vertex_samples) and the
  * Russian-roulette number from an index permuted alongside (cmj_next_with_index).  This entry point runs exactly that code
  * — and the one-by-one calls where the kernels fall back to them — so that "sample indices bit-exact" is asserted on the
- * instructions the renders execute.  `integrator` = ZDR_PATH or ZDR_DIRECT: the pixel's 2-D draw is packed for both (an
- * index pass + one packed pass for its two strata, csrc/sampler.h cmj_next2_packed); the direct kernels then draw the
- * vertex's numbers one by one (packed passes cost them more in register spills than they save).  Other arguments and the output
+ * instructions the renders execute.  `integrator` = ZDR_PATH or ZDR_DIRECT: the direct kernels pack the PIXEL's 2-D draw
+ * (an index pass + one packed pass for its two strata, csrc/sampler.h cmj_next2_packed) and draw the vertex's numbers one
+ * by one; the path kernels draw the pixel's numbers one by one and pack the vertex's (each kernel keeps the form that
+ * its register budget pays for: csrc/integrators.h, pixel_ray).  Other arguments and the output
  * layout as zdr_sampler_dump; *batched (HOST, may be NULL) receives 1 when the packed route was taken, 0 for the fallback. */
 int zdr_vertex_sampler_dump(zdr_scene *scene, int32_t integrator, int32_t sampler, uint32_t seed, uint32_t spp,
                             const int32_t *queries, uint32_t n, int32_t nvert, int32_t rr_depth, float *out,

@@ -45,7 +45,7 @@ def test_cmj_draws_of_the_path_kernels_bit_exact(spp):
             assert exp.shape[0] == 2 + 7 * nvert + (nvert - 2)      # next2f, seven per vertex, a roulette draw from vertex 2 on
             assert (got[k, :exp.shape[0]].view(np.uint32) == exp.view(np.uint32)).all(), (spp, seed, q[k])
         # and the routes of the library agree with each other on every draw: one by one, as the path kernels group them, as the direct kernels do
-        # (direct_sample: the pixel's draw packed, the vertex's numbers one by one)
+        # (direct kernels: the pixel's draw packed, the vertex's numbers one by one; path kernels: the other way round)
         plain = scene.sampler_dump(torch.from_numpy(q).cuda(), spp, seed=seed, nvert=nvert).cpu().numpy()
         assert (plain.view(np.uint32) == got.view(np.uint32)).all(), (spp, seed)
         as_direct, b2 = scene.vertex_sampler_dump(torch.from_numpy(q).cuda(), spp, seed=seed, nvert=nvert, integrator="direct")

@@ -14,9 +14,12 @@ ZD float tent_warp1(float u) {                                   // camera.py:20
 }
 
 // integrator.py:19-24 + camera.py:5-17
-template <int SK>
+// PACKED: the pixel's 2-D draw in two hash passes instead of three (sampler.h, cmj_next2_packed; same values).  The direct / collocated kernels take it
+// (direct forward 0.898 -> 0.873 ms); the path kernels do NOT: there it buys nothing (the camera samples are 7 % of their instructions) and, in the BVH forward
+// kernel, which lives at 80 VGPRs, it moved five spill operations INTO the walk loop: 184 -> 199 ms on the 1 M-triangle scene (round 4, measured).
+template <int SK, bool PACKED = false>
 ZD void pixel_ray(const RenderCfg &R, const SamplerCfg &C, Sampler &smp, int x, int y, f3 &o, f3 &d) {
-    f2 off = sampler_pixel_offset<SK>(C, smp);
+    f2 off = PACKED ? sampler_pixel_offset<SK>(C, smp) : sampler_next2<SK>(C, smp);
     if (R.use_tent) { off.x = tent_warp1(off.x) + 0.5f; off.y = tent_warp1(off.y) + 0.5f; }
     float px = R.two_over_w * ((float)x + off.x) - 1.0f;
     float py = R.two_over_h * ((float)y + off.y) - 1.0f;

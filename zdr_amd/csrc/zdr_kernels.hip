@@ -614,7 +614,7 @@ __global__ __launch_bounds__(WAVE, (INTEG == ZDR_DIRECT && !A::kNeedsLds) ? (ENV
         if (w.valid) {
             Sampler smp = sampler_make<SK>(C, (uint32_t)w.x, (uint32_t)w.y, perm_seed, it);
             f3 o, d;
-            pixel_ray<SK>(R, C, smp, w.x, w.y, o, d);
+            pixel_ray<SK, true>(R, C, smp, w.x, w.y, o, d);
             COUNT(C_SAMPLES);
             f3 rad;
             if (INTEG == ZDR_COLLOCATED) rad = collocated_sample<A, BWD, STATS>(S, R, io, lds, o, d, cam_mask, le_grad, cnt, guv, grad);
@@ -988,7 +988,7 @@ __global__ void k_vertex_sampler_dump(SamplerCfg C, const int32_t *q, uint32_t n
     const int stride = 2 + 8 * nvert;
     float *o = out + (size_t)i * stride;
     int k = 0;
-    f2 u = sampler_pixel_offset<SK>(C, s); o[k++] = u.x; o[k++] = u.y;       // pixel_ray's draw
+    f2 u = direct ? sampler_pixel_offset<SK>(C, s) : sampler_next2<SK>(C, s); o[k++] = u.x; o[k++] = u.y;       // pixel_ray's draw: packed in the direct kernels only
     const bool pre = (SK == 0) && cmj_can_batch(C);             // shade_ctx's x.pre (without an environment light)
     for (int v = 0; v < nvert; v++) {
         if (pre && direct) {                                    // direct_sample (integrators.h): after the packed pixel draw, the calls one by one

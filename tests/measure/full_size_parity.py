@@ -14,15 +14,22 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=512)
 ap.add_argument("--spp", type=int, default=256)
 ap.add_argument("--shards", type=int, default=1, help="render the GPU side as this many interleaved tile shards (BASELINE configs[3]) and compare their union / sum")
+ap.add_argument("--scene", default="cbox", choices=["cbox", "tess1m"], help="tess1m: BASELINE configs[4], the 1,004,672-triangle tessellated Cornell box (BVH)")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "full_size_parity.json"))
 a = ap.parse_args()
 W, spp, seed = a.res, a.spp, 7
 mat = cbox_material_np()
-A = geometry.assemble(cbox_models())
+if a.scene == "tess1m":
+    from zdr_amd.scenes import tess1m_arrays
+    A = tess1m_arrays()
+    scene = make_scene("path", arrays=A)
+    assert scene.info()["accel"] == "bvh"
+else:
+    A = geometry.assemble(cbox_models())
+    scene = make_scene("path")
 S, Sf = oracle.OracleScene.from_arrays(A), oracle.OracleScene.from_arrays(A, variant="fma")
-scene = make_scene("path")
 m = torch.from_numpy(mat).cuda()
-out = {"config": f"cbox path {W}x{W} spp {spp} seed {seed}, cboxd/cboxr textures" + (f", GPU side = union of {a.shards} interleaved tile shards" if a.shards > 1 else "")}
+out = {"config": f"{'1,004,672-triangle tessellated cbox' if a.scene == 'tess1m' else 'cbox'} path {W}x{W} spp {spp} seed {seed}, cboxd/cboxr textures" + (f", GPU side = union of {a.shards} interleaved tile shards" if a.shards > 1 else "")}
 t = time.time()
 if a.shards > 1:
     img_t = torch.zeros((W, W, 4), device="cuda")

@@ -103,6 +103,26 @@ def test_forward_and_backward_match_the_oracle(material, million):
     assert_grad_parity(g, gref, f"1M triangles backward {material}", flips=fb, floor=Sf.render_backward(pb, cot, mat) if glossy else None)
 
 
+def test_c5_at_its_real_resolution(million):
+    """BASELINE configs[4] at 1024 x 1024 (spp 16 instead of 256: 16.8 M camera samples per pass, what the oracle's own BVH follows in
+    seconds on the box's host cores; the full 268 M-sample configuration is profiles/r4_full_size_parity_c5.json: image 2.9e-5, gradient
+    9.2e-5 beside an FMA ruler of 2.1e-5 / 7.9e-5).  Image and gradient as a whole against the oracle; on 6 mm triangles a hit next to a
+    shared edge lands on either neighbour in any two float32 evaluations, so the bars are the ruler's (the oracle's own FMA build), as for
+    the glossy inputs (tests/gpu_util.py) — at this size no per-path dump can set the flipped paths aside."""
+    A, scene, S, Sf = million
+    mat = cbox_material_np()
+    W, spp, seed = 1024, 16, 9
+    m = torch.from_numpy(mat).cuda().requires_grad_()
+    cot = np.random.default_rng(4).uniform(0.5, 1.5, (W, W, 4)).astype(np.float32)
+    img = scene.render(m, res=(W, W), spp=spp, seed=seed)
+    (img * torch.from_numpy(cot).cuda()).sum().backward()
+    scene.check()
+    pf, pb = oracle_params(scene, W, W, spp, seed, mat.shape[:2]), oracle_params(scene, W, W, spp, seed + 1, mat.shape[:2])
+    assert_image_parity(img.detach().cpu().numpy()[..., :3], S.render_forward(pf, mat)[..., :3], "c5 1M triangles 1024^2 spp 16 forward",
+                        floor=Sf.render_forward(pf, mat)[..., :3])
+    assert_grad_parity(m.grad.cpu().numpy(), S.render_backward(pb, cot, mat), "c5 1M triangles 1024^2 spp 16 backward", floor=Sf.render_backward(pb, cot, mat))
+
+
 def test_ad_matches_fd_on_the_million_triangle_scene(million):
     """BASELINE.json: 'gradients within 1e-3 rel of fd_validate.py' — on the BVH instantiation of the kernels and a
     displaced surface (shading normals differ from geometric ones almost everywhere)."""

@@ -26,6 +26,8 @@ ap.add_argument("--tiles", type=int, default=24)
 ap.add_argument("--n", type=int, default=183)
 ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--steal-trips", type=int, default=1)
+ap.add_argument("--period", type=int, default=1, help="lanes may steal only in every period-th trip")
+ap.add_argument("--lds-entries", type=int, default=0, help="> 0: only the first N stack entries of a lane (the LDS part) can be taken")
 ap.add_argument("--min-victim", type=int, default=2, help="a lane is a victim only with at least this many stack entries")
 ap.add_argument("--share-best", action="store_true", help="all lanes working for a ray see its best hit distance (an LDS cell per lane)")
 a = ap.parse_args()
@@ -156,7 +158,7 @@ def run_wave(lanes, steal):
                 t.ray.workers -= 1
                 task[l] = None
                 next_own(l)
-        if steal:
+        if steal and trips % a.period == 0:
             for l in range(len(lanes)):
                 if task[l] is not None or wait[l] > 0 or todo[l]:
                     continue

@@ -30,7 +30,7 @@
 #define ZDR_POOL_SLOTS 103            // brute force: 10,176 bytes of LDS per wave (103 x 81 + the scatter queue + 48)
 #endif
 #ifndef ZDR_POOL_SLOTS_BVH
-#define ZDR_POOL_SLOTS_BVH 72         // BVH: + the traversal stack (ZDR_BVH_LDS_STACK_BWD entries x 256 bytes), 8 blocks as well
+#define ZDR_POOL_SLOTS_BVH 56         // BVH: + the traversal stack (ZDR_BVH_LDS_STACK_BWD entries x 256 bytes) + the 1,280 bytes of walk_steal, 8 blocks as well (72 slots before stealing; 62 slots + 8 stack entries and 48 + 12 measured 1 % slower)
 #endif
 #ifndef ZDR_MIN_WAVES_BWD_BVH
 #define ZDR_MIN_WAVES_BWD_BVH 4
@@ -314,7 +314,7 @@ struct BvhAccel {
         if (w.cnt > 1) { f.n4 = p[4]; f.n5 = p[5]; }
         return f;
     }
-    ZD static bool consume(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const Fetched &f, const bool anyhit) {
+    ZD static bool consume(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const Fetched &f, const bool anyhit, const int bot = 0) {
         const int lane = threadIdx.x & 63;
         bool ray_done = f.dead;
         const f3 o = w.o, d = w.d, inv = w.inv; const float tmin = w.tmin;
@@ -376,7 +376,7 @@ struct BvhAccel {
 #endif
             if (anyhit && w.h.slot >= 0) ray_done = true;         // any-hit: the first hit settles it
         }
-        if (!ray_done && w.sp != 0) {
+        if (!ray_done && w.sp != bot) {               // (bot: entries below it were taken by other lanes, walk_steal; 0 otherwise)
             w.sp--;
             // The pop is on the critical path of every trip.  Written as one conditional expression the compiler merges the LDS and the
             // scratch access into a FLAT load (generic pointer, aperture check, vector-memory issue and latency even for the LDS case);
@@ -389,9 +389,9 @@ struct BvhAccel {
         }
         return false;
     }
-    ZD static bool step(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const bool anyhit) {
+    ZD static bool step(const DScene &S, int *stack, const int LN, int *deep, Walker &w, const bool anyhit, const int bot = 0) {
         const Fetched f = fetch(S, stack, w);
-        return consume(S, stack, LN, deep, w, f, anyhit);
+        return consume(S, stack, LN, deep, w, f, anyhit, bot);
     }
     // One loop walks up to two rays per lane back to back: first (HAS_A) an any-hit ray — the shadow segment of a
     // path vertex — then (HAS_B, lanes with needB) a closest-hit ray — the continuation ray.  A lane starts its second
@@ -427,6 +427,98 @@ struct BvhAccel {
         }
         if (HAS_B && needB) { hit = w.h; if (hit.slot >= 0) hit.slot = slot_of(S, hit.slot); hit_barycentrics(S, hit, oB, dB); }
     }
+#if ZDR_BVH_STEAL
+    // The fused walk with SUBTREE STEALING (round 4; costed in profiles/r4_steal_sim.txt, measured in profiles/r4_subtree_stealing.txt).  The
+    // wave's trip count is set by its slowest lane — 67 trips for 40 visits of the mean lane on the 1 M-triangle scene — and the stacks of all
+    // lanes live in the wave's LDS.  So a lane that is through takes the BOTTOM entry (the farthest subtree still waiting) of the LDS stack of a
+    // lane that still has entries there — every ZDR_BVH_STEAL-th trip, the k-th idle lane from the k-th lane with entries, matched through a
+    // 64-entry LDS list — and walks that subtree with a copy of the owner's ray (nine ds_bpermute: no LDS held for rays).  A robbed lane learns
+    // its new bottom from LDS after the steal trip (consume() pops down to `bot`, not to 0).  Every hit goes to the LDS cell of the lane that
+    // OWNS the ray — ds_min_u64 on {t, record} for the closest-hit ray, ds_or for the any-hit ray — and that is where the results are read when
+    // the loop ends; on steal trips a closest-hit walker also takes over the best distance the others have found.  The answers are those of
+    // walk(): the same triangles are tested against the same rays by the same code, only by other lanes (min over {t, record} instead of "first
+    // found" decides an exact tie of two triangles, which needs a ray through a shared edge to the last bit); images and gradients of the c5
+    // bench are identical to the last digit printed with and without; tests/test_gpu_c5.py compares every path of 73,728 with the oracle.
+    // LDS beyond the stack's LN x 64 ints (bvh_dyn_lds, zdr_kernels.hip): cellB 64 x u64, cellA 64, bottoms 64, match list 64 ints = 1,280 bytes.
+    typedef __attribute__((address_space(3))) int lds_i32;
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    ZD static float pull(int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
+    ZD static uint32_t rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
+    template <bool HAS_A, bool HAS_B>
+    ZD static void walk_steal(const DScene &S, int *stack, f3 oA, f3 dA, float tminA, float tmaxA,
+                              bool needB, f3 oB, f3 dB, float tminB, float tmaxB, bool &occ, Hit &hit, bool needA = true) {
+        const int lane = threadIdx.x & 63;
+        const int LN = S.lds_stack;
+        lds_i32 *stk = (lds_i32 *)stack;
+        lds_u64 *cellB = (lds_u64 *)(stk + LN * 64);
+        lds_i32 *cellA = stk + LN * 64 + 128, *lbot = cellA + 64, *llist = cellA + 128;
+        cellB[lane] = ((unsigned long long)__float_as_uint(tmaxB) << 32) | 0xffffffffull;
+        cellA[lane] = 0; lbot[lane] = 0;
+        bool first = HAS_A && needA;
+        bool active = first || (HAS_B && needB);
+        bool mine = true;                                    // the lane is on its own rays (not on a subtree it took)
+        int owner = lane, bot = 0;
+        int deep[ZDR_BVH_STACK];
+        Walker w;
+        if (first) start(S, w, oA, dA, tminA, tmaxA); else start(S, w, oB, dB, tminB, tmaxB);
+        auto end_task = [&]() {                              // this lane's current ray (or the subtree it took) is through
+            if (mine && first && HAS_B && needB) { first = false; start(S, w, oB, dB, tminB, tmaxB); bot = 0; lbot[lane] = 0; }
+            else active = false;
+        };
+        int trips_left = ((HAS_A && HAS_B) ? 2 : 1) * walk_budget(S);
+        while (__ballot(active) != 0ull) {
+            if (--trips_left < 0) { raise_device_error(S, ZDR_DEVERR_BVH_BUDGET); break; }
+            if (active) {
+                const float t0 = w.h.t;
+                const bool more = step(S, stack, LN, deep, w, first, bot);
+                if (w.h.t != t0) {                           // a hit: to the owner's cell
+                    if (first) __hip_atomic_fetch_or(cellA + owner, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    else __hip_atomic_fetch_min(cellB + owner, ((unsigned long long)__float_as_uint(w.h.t) << 32) | (unsigned int)w.h.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                if (!more) end_task();
+            }
+            if ((trips_left % ZDR_BVH_STEAL) == 0) {
+                const unsigned long long im = __ballot(!active);
+                const bool cand = active && (((w.sp < LN) ? w.sp : LN) - bot) >= ZDR_BVH_STEAL_MIN;
+                const unsigned long long cm = __ballot(cand);
+                if (im != 0ull && cm != 0ull) {              // wave-uniform
+                    if (cand) llist[rank_in(cm)] = lane;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int r = (int)rank_in(im);
+                    const bool thief = !active && r < __popcll(cm);
+                    const int victim = thief ? llist[r] : lane;
+                    const int va = victim << 2;
+                    const f3 vo = mk3(pull(va, w.o.x), pull(va, w.o.y), pull(va, w.o.z)), vd = mk3(pull(va, w.d.x), pull(va, w.d.y), pull(va, w.d.z));
+                    const float vtmin = pull(va, w.tmin), vt = pull(va, w.h.t);
+                    const int vbot = __builtin_amdgcn_ds_bpermute(va, bot), vowner = __builtin_amdgcn_ds_bpermute(va, owner), vfirst = __builtin_amdgcn_ds_bpermute(va, first ? 1 : 0);
+                    if (thief) {
+                        const int e = stk[vbot * 64 + victim];
+                        lbot[victim] = vbot + 1;
+                        lbot[lane] = 0;
+                        w.o = vo; w.d = vd; w.inv = mk3(rcp(vd.x), rcp(vd.y), rcp(vd.z)); w.tmin = vtmin;
+                        w.h.t = vt; w.h.slot = -1; w.h.u = 0.0f; w.h.v = 0.0f;
+                        w.sp = 0; bot = 0; w.off = (uint32_t)e & ~15u; w.cnt = e & 7;
+                        owner = vowner; first = vfirst != 0; mine = false; active = true;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (cand) bot = lbot[lane];
+                }
+                // what the others found for this lane's ray meanwhile prunes its walk as well
+                if (active && !first) w.h.t = fminf(w.h.t, __uint_as_float((uint32_t)(cellB[owner] >> 32)));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        occ = HAS_A && needA && cellA[lane] != 0;
+        hit.slot = -1; hit.u = 0.0f; hit.v = 0.0f; hit.t = tmaxB;
+        if (HAS_B && needB) {
+            const unsigned long long c = cellB[lane];
+            hit.t = __uint_as_float((uint32_t)(c >> 32));
+            const int units = (int)(uint32_t)c;
+            if (units >= 0) hit.slot = slot_of(S, units);
+            hit_barycentrics(S, hit, oB, dB);
+        }
+    }
+#endif
     ZD static Hit closest(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) {
         bool occ; Hit h;
         walk<false, true>(S, stack, o, d, tmin, tmax, true, o, d, tmin, tmax, occ, h);
@@ -440,6 +532,10 @@ struct BvhAccel {
     ZD static bool any_shadow(const DScene &S, int *stack, f3 o, f3 d, float tmin, float tmax) { return any(S, stack, o, d, tmin, tmax); }
     // need1: the lane has a shadow ray (o1, d1) at all; need2: it has a continuation ray (o2, d2)
     ZD static void shadow_and_closest(const DScene &S, int *stack, bool need1, f3 o1, f3 d1, float tmin1, float tmax1, bool need2, f3 o2, f3 d2, bool &occ, Hit &h) {
+#if ZDR_BVH_STEAL
+        walk_steal<true, true>(S, stack, o1, d1, tmin1, tmax1, need2, o2, d2, 0.0f, 1e30f, occ, h, need1);
+#else
         walk<true, true>(S, stack, o1, d1, tmin1, tmax1, need2, o2, d2, 0.0f, 1e30f, occ, h, need1);
+#endif
     }
 };

@@ -5,6 +5,12 @@
 #include "vecmath.h"
 
 // largest leaf of the BVH builder (zdr_api.cpp); the walk fetches two triangles with the node fetch and loops over any further ones
+#ifndef ZDR_BVH_STEAL
+#define ZDR_BVH_STEAL 2     // subtree stealing in the fused walk of the BVH path kernels (accel.h, walk_steal): lanes that are through may take work in every
+#endif                      // ZDR_BVH_STEAL-th trip (0: off).  1 M triangles, path 1024^2 spp 32, forward / backward ms: off 23.7 / 29.9, every trip 21.2 / 27.4, 2nd 20.9 / 26.8, 4th 21.6 / 27.7
+#ifndef ZDR_BVH_STEAL_MIN
+#define ZDR_BVH_STEAL_MIN 1 // a lane can be robbed while it has this many entries in the LDS part of its stack (2: forward 22.3 instead of 21.1 ms; 3: 23.5)
+#endif
 #ifndef ZDR_BVH_LEAF
 #define ZDR_BVH_LEAF 2   // 1 M triangles, path fwd / bwd ms at 1024^2 spp 32: leaf 1: 46 / 61, 2: 42 / 56, 3: 43 / 58, 4: 48 / 64, 6: 54 / 72 (a triangle costs three per-lane loads, a node four)
 #endif

@@ -732,9 +732,10 @@ int zdr_launch_zero(void *p, size_t bytes, hipStream_t st) {
 
 // ----------------------------------------------------------------------------------- launch
 // dynamic LDS of a wave that traverses the BVH: the first entries of the per-lane stacks (accel.h).  Sets S.lds_stack.
-static size_t bvh_dyn_lds(DScene &S, bool backward) {
+// path_kernels: the launch runs BvhAccel::shadow_and_closest (k_path, k_path_bwd, k_path_dump), whose walk_steal keeps 5 x 64 ints behind the stack.
+static size_t bvh_dyn_lds(DScene &S, bool backward, bool path_kernels) {
     S.lds_stack = std::min<int>(S.stack_entries, backward ? ZDR_BVH_LDS_STACK_BWD : ZDR_BVH_LDS_STACK);
-    return (size_t)S.lds_stack * WAVE * sizeof(int);
+    return (size_t)S.lds_stack * WAVE * sizeof(int) + ((ZDR_BVH_STEAL && path_kernels) ? 5 * WAVE * sizeof(int) : 0);
 }
 // Persistent grid of the path kernels: as many single-wave workgroups as the chip holds at once (never more
 // than there are items).  A workgroup that is not resident at first simply starts later and draws what is left.
@@ -812,7 +813,7 @@ int zdr_launch_render(const DScene &S_in, const RenderCfg &R, const SamplerCfg &
     int nblocks = R.ntiles * R.nchunks;
     if (nblocks <= 0) return 0;
     dim3 grid(((nblocks + 7) >> 3) << 3);                   // multiple of 8 for the XCD remap
-    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S, backward != 0) : 0;
+    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S, backward != 0, integrator == ZDR_PATH) : 0;
     if (io.tile_masks && !io.tile_masks_valid)
         hipLaunchKernelGGL(k_tile_masks, dim3(R.tiles_x * R.tiles_y), dim3(WAVE), 0, st, S, R, (unsigned long long *)io.tile_masks);
     if (C.kind == ZDR_SAMPLER_CMJ) {
@@ -866,7 +867,7 @@ int zdr_launch_trace(const DScene &S_in, int accel_is_bvh, int any, const float 
     dim3 grid((n + WAVE - 1) / WAVE);
     const float4 *r = (const float4 *)rays;
     if (accel_is_bvh) {
-        const size_t dyn = bvh_dyn_lds(S, false);
+        const size_t dyn = bvh_dyn_lds(S, false, false);
         if (any) hipLaunchKernelGGL((k_trace<BvhAccel, true>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
         else hipLaunchKernelGGL((k_trace<BvhAccel, false>), grid, dim3(WAVE), dyn, st, S, r, n, out_i, out_f);
     } else {
@@ -944,7 +945,7 @@ int zdr_launch_path_dump(const DScene &S_in, const RenderCfg &R, const SamplerCf
     DScene S = S_in;
     if (n == 0) return 0;
     dim3 grid((n + WAVE - 1) / WAVE);
-    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S, true) : 0;
+    const size_t dyn = accel_is_bvh ? bvh_dyn_lds(S, true, true) : 0;
 #define ZDR_DUMP(SKV, ACC, ENVV) hipLaunchKernelGGL((k_path_dump<SKV, ACC, ENVV>), grid, dim3(WAVE), dyn, st, S, R, C, io, queries, n, maxv, out)
     const bool env = S.env_count > 0, cmj = C.kind == ZDR_SAMPLER_CMJ;
     if (accel_is_bvh) { if (cmj) { if (env) ZDR_DUMP(0, BvhAccel, true); else ZDR_DUMP(0, BvhAccel, false); } else { if (env) ZDR_DUMP(1, BvhAccel, true); else ZDR_DUMP(1, BvhAccel, false); } }

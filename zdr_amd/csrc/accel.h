@@ -16,7 +16,7 @@
 #define ZDR_MIN_WAVES_ENV 4    // the environment-light instantiation: 10 registers spilled at 4, still 11.9 -> 11.4 ms
 #endif
 #ifndef ZDR_MIN_WAVES_BVH
-#define ZDR_MIN_WAVES_BVH 6    // 1 M triangles, forward ms at 1024^2 spp 32 with 4 / 5 / 6 / 7 / 8 waves per SIMD: 32.8 / 31.4 / 30.3 / 31.4 / 39.4
+#define ZDR_MIN_WAVES_BVH 5    // 1 M triangles, forward ms at 1024^2 spp 32 with 4 / 5 / 6 waves per SIMD since the walk steals subtrees (walk_steal: more live state in the loop): 21.7 / 20.6 / 21.0 (round 2, 4 / 5 / 6 / 7 / 8 waves: 32.8 / 31.4 / 30.3 / 31.4 / 39.4)
 #endif
 // The backward path kernel's waves per CU are decided by LDS, which gfx950 hands out in 128 blocks of 1,280 bytes per CU:
 // 16 waves = 8 blocks = 10,240 bytes per wave.  The kernel keeps neither the CMJ seeds nor the pixel cotangents of its two item
@@ -260,7 +260,7 @@ ZD float qbox_entry(uint32_t nxq, uint32_t nyq, uint32_t nzq, uint32_t fxq, uint
 struct BvhAccel {
     static constexpr bool kNeedsLds = true;
     static constexpr int kMinWavesFwdEnv = ZDR_MIN_WAVES_BVH;
-    static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // 6 waves per SIMD (<= 80 VGPRs: the path state that is cold during the walk is spilled around it); sweep at ZDR_MIN_WAVES_BVH
+    static constexpr int kMinWavesFwd = ZDR_MIN_WAVES_BVH;   // 5 waves per SIMD (<= 96 VGPRs: the path state that is cold during the walk is spilled around it); sweep at ZDR_MIN_WAVES_BVH
     static constexpr int kMinWavesBwd = ZDR_MIN_WAVES_BWD_BVH;   // backward: LDS decides the waves per CU; one record in LDS and
     static constexpr int kPoolSlots = ZDR_POOL_SLOTS_BVH;
     ZD static Hit closest_camera(const DScene &S, int *stack, f3 o, f3 d, unsigned long long) { return closest(S, stack, o, d, 0.0f, 1e30f); }
